@@ -1,0 +1,428 @@
+"""Straight-line C emission for the residual models (sympy -> CSE -> C).
+
+Two flavours are produced from the SAME symbolic statement:
+
+* ``oracle`` : plain C99, ``double`` only, dense column-major Jacobians -- consumed by the CPU
+  restatement under ``oracle/`` (test infrastructure).
+* ``device`` : templated ``OD_HD`` (host/device) inline functions on sparse Jacobian value arrays,
+  plus a statically ordered sparse elimination of the KKT matrix with a small runtime-pivoted
+  dense tail -- consumed by the HIP kernels under ``optimization_dynamics_amd/csrc``.
+
+This is the counterpart of ``Symbolics.build_function(...)[2]`` in the reference's
+``src/models/*/codegen.jl`` (e.g. acrobot/codegen.jl:18-31).
+"""
+from __future__ import annotations
+
+import io
+from typing import Dict, List, Sequence, Tuple
+
+import sympy as sp
+from sympy.printing.c import C99CodePrinter
+
+from .models import ModelSpec
+
+
+# --------------------------------------------------------------------------------------
+# printers
+# --------------------------------------------------------------------------------------
+class _OraclePrinter(C99CodePrinter):
+    def _print_Pow(self, expr):
+        b, e = expr.base, expr.exp
+        if e.is_Integer and 2 <= int(e) <= 12:
+            return "od_powi(%s, %d)" % (self._print(b), int(e))
+        if e.is_Integer and -12 <= int(e) <= -1:
+            if int(e) == -1:
+                return "(1.0/(%s))" % self._print(b)
+            return "(1.0/od_powi(%s, %d))" % (self._print(b), -int(e))
+        return super()._print_Pow(expr)
+
+
+class _DevicePrinter(C99CodePrinter):
+    """Prints with scalar type ``T``: literals wrapped, math functions overloaded (od_sin...)."""
+
+    def _print_Float(self, expr):
+        s = super()._print_Float(expr)
+        return "T(%s)" % s
+
+    def _print_Integer(self, expr):
+        return "T(%d)" % int(expr)
+
+    def _print_Rational(self, expr):
+        return "(T(%d)/T(%d))" % (int(expr.p), int(expr.q))
+
+    def _print_Pi(self, expr):
+        return "T(3.14159265358979323846)"
+
+    def _print_Pow(self, expr):
+        b, e = expr.base, expr.exp
+        if e.is_Integer and 2 <= int(e) <= 12:
+            return "od_powi<%d>(%s)" % (int(e), self._print(b))
+        if e.is_Integer and -12 <= int(e) <= -1:
+            if int(e) == -1:
+                return "(T(1)/(%s))" % self._print(b)
+            return "(T(1)/od_powi<%d>(%s))" % (-int(e), self._print(b))
+        if e == sp.Rational(1, 2):
+            return "od_sqrt(%s)" % self._print(b)
+        if e == -sp.Rational(1, 2):
+            return "(T(1)/od_sqrt(%s))" % self._print(b)
+        return "od_pow(%s, %s)" % (self._print(b), self._print(e))
+
+    def _print_sin(self, expr):
+        return "od_sin(%s)" % self._print(expr.args[0])
+
+    def _print_cos(self, expr):
+        return "od_cos(%s)" % self._print(expr.args[0])
+
+    def _print_Abs(self, expr):
+        return "od_abs(%s)" % self._print(expr.args[0])
+
+
+def _cse_block(exprs: Sequence[sp.Expr], printer, scalar: str, prefix: str) -> Tuple[List[str], List[str]]:
+    """CSE the expressions; returns (statement lines, printed result expressions)."""
+    syms = sp.numbered_symbols(prefix)
+    repl, red = sp.cse(list(exprs), symbols=syms, optimizations="basic")
+    lines = []
+    for s, e in repl:
+        lines.append("const %s %s = %s;" % (scalar, s.name, printer.doprint(e)))
+    outs = [printer.doprint(e) for e in red]
+    return lines, outs
+
+
+def count_ops(exprs: Sequence[sp.Expr]) -> int:
+    repl, red = sp.cse(list(exprs), optimizations="basic")
+    return int(sum(sp.count_ops(e) for _, e in repl) + sum(sp.count_ops(e) for e in red))
+
+
+# --------------------------------------------------------------------------------------
+# symbolic derivation shared by both flavours
+# --------------------------------------------------------------------------------------
+class Derived:
+    def __init__(self, m: ModelSpec):
+        self.m = m
+        r = sp.Matrix(m.r)
+        self.r = r
+        self.rz = r.jacobian(sp.Matrix(m.z))
+        self.rth = r.jacobian(sp.Matrix(m.th))
+        # kappa enters linearly with coefficient -1 on the cone "head" rows only
+        dk = r.diff(m.kappa)
+        self.kappa_rows = [i for i in range(m.nz) if dk[i] != 0]
+        heads = list(m.ortr) + [s[0] for s in m.socri]
+        assert sorted(self.kappa_rows) == sorted(heads), (m.name, self.kappa_rows, heads)
+        for i in self.kappa_rows:
+            assert dk[i] == -1
+        self.r0 = r.subs(m.kappa, 0)
+        self.rz_nz = [(i, j) for i in range(m.nz) for j in range(m.nz) if self.rz[i, j] != 0]
+        # gradient columns of theta actually consumed by the callers
+        if m.kind == "mech":
+            self.grad_cols = list(range(2 * m.nq + m.nu))
+        elif m.kind == "rocket":
+            self.grad_cols = list(range(m.nq + m.nu))
+        else:
+            self.grad_cols = list(range(3))
+        self.rth_nz = [(i, j) for j in self.grad_cols for i in range(m.nz) if self.rth[i, j] != 0]
+        # can the regularisation clamp (z_ort -> max(z_ort, reg) inside rz) be applied after
+        # evaluation?  yes iff orthant variables enter rz only through their own bilinear rows.
+        ortv = set(m.ort[0]) | set(m.ort[1])
+        ok = True
+        self.ort_entries = []  # (nnz index, partner variable index) for bilinear-row entries
+        for k, (i, j) in enumerate(self.rz_nz):
+            e = self.rz[i, j]
+            deps = {m.z.index(s) for s in e.free_symbols if s in m.z}
+            if deps & ortv:
+                if i in m.ortr and e in [m.z[v] for v in ortv]:
+                    self.ort_entries.append((k, m.z.index(e)))
+                else:
+                    ok = False
+        self.reg_posthoc = ok
+
+
+# --------------------------------------------------------------------------------------
+# oracle flavour
+# --------------------------------------------------------------------------------------
+def emit_oracle(m: ModelSpec, d: Derived) -> str:
+    pr = _OraclePrinter()
+    o = io.StringIO()
+    n = m.name
+    o.write("/* GENERATED by optimization_dynamics_amd.codegen (oracle flavour) -- do not edit.\n")
+    o.write(" * Model %s: nz=%d ntheta=%d.  Test infrastructure only. */\n" % (n, m.nz, m.nth))
+
+    def func(sig, exprs, outname, dense_idx=None, zero=None):
+        o.write("static void %s {\n" % sig)
+        if zero:
+            o.write("  for (int i_ = 0; i_ < %d; ++i_) %s[i_] = 0.0;\n" % (zero, outname))
+        lines, outs = _cse_block(exprs, pr, "double", "x")
+        for ln in lines:
+            o.write("  " + ln + "\n")
+        for k, e in enumerate(outs):
+            idx = dense_idx[k] if dense_idx is not None else k
+            o.write("  %s[%d] = %s;\n" % (outname, idx, e))
+        o.write("}\n\n")
+
+    sub = {s: sp.Symbol("z[%d]" % i) for i, s in enumerate(m.z)}
+    sub.update({s: sp.Symbol("th[%d]" % i) for i, s in enumerate(m.th)})
+
+    def S(e):
+        return e.subs(sub, simultaneous=True)
+
+    func("%s_r(const double* z, const double* th, double kappa, double* r)" % n,
+         [S(e) for e in d.r], "r")
+    func("%s_rz(const double* z, const double* th, double* rz)" % n,
+         [S(d.rz[i, j]) for (i, j) in d.rz_nz], "rz",
+         dense_idx=[i + m.nz * j for (i, j) in d.rz_nz], zero=m.nz * m.nz)
+    nzth = [(i, j) for j in range(m.nth) for i in range(m.nz) if d.rth[i, j] != 0]
+    func("%s_rth(const double* z, const double* th, double* rth)" % n,
+         [S(d.rth[i, j]) for (i, j) in nzth], "rth",
+         dense_idx=[i + m.nz * j for (i, j) in nzth], zero=m.nz * m.nth)
+    return o.getvalue()
+
+
+def _c_int_list(xs):
+    return "{" + ", ".join(str(int(x)) for x in xs) + "}" if len(xs) else "{0}"
+
+
+def emit_oracle_table(m: ModelSpec) -> str:
+    """Static description consumed by oracle/ip_oracle.c (struct od_oracle_model)."""
+    n = m.name
+    o = io.StringIO()
+    soc_flat_p, soc_flat_d, soc_off, socr_flat = [], [], [0], []
+    for (p, dd), rr in zip(m.soc, m.socri):
+        soc_flat_p += p
+        soc_flat_d += dd
+        socr_flat += rr
+        soc_off.append(len(soc_flat_p))
+    zi_kind = [0 if isinstance(e, tuple) else 1 for e in m.z_init]
+    zi_idx = [e[1] if isinstance(e, tuple) else 0 for e in m.z_init]
+    zi_val = [0.0 if isinstance(e, tuple) else float(e) for e in m.z_init]
+    o.write("static const int %s_ort1[] = %s;\n" % (n, _c_int_list(m.ort[0])))
+    o.write("static const int %s_ort2[] = %s;\n" % (n, _c_int_list(m.ort[1])))
+    o.write("static const int %s_ortr[] = %s;\n" % (n, _c_int_list(m.ortr)))
+    o.write("static const int %s_soc1[] = %s;\n" % (n, _c_int_list(soc_flat_p)))
+    o.write("static const int %s_soc2[] = %s;\n" % (n, _c_int_list(soc_flat_d)))
+    o.write("static const int %s_socr[] = %s;\n" % (n, _c_int_list(socr_flat)))
+    o.write("static const int %s_socoff[] = %s;\n" % (n, _c_int_list(soc_off)))
+    o.write("static const int %s_equr[] = %s;\n" % (n, _c_int_list(m.equr)))
+    o.write("static const int %s_bil[] = %s;\n" % (n, _c_int_list(m.bil)))
+    o.write("static const int %s_zq[] = %s;\n" % (n, _c_int_list(m.idx_zq)))
+    o.write("static const int %s_zikind[] = %s;\n" % (n, _c_int_list(zi_kind)))
+    o.write("static const int %s_ziidx[] = %s;\n" % (n, _c_int_list(zi_idx)))
+    o.write("static const double %s_zival[] = {%s};\n" % (n, ", ".join(repr(v) for v in zi_val)))
+    fd = m.fric_default if m.fric_default else [0.0]
+    o.write("static const double %s_fric[] = {%s};\n" % (n, ", ".join(repr(float(v)) for v in fd)))
+    kind = {"mech": 0, "rocket": 1, "proj": 2}[m.kind]
+    op = m.opts
+    und = "INFINITY" if op["undercut"] == float("inf") else repr(float(op["undercut"]))
+    o.write("static const od_oracle_model %s_model = {\n" % n)
+    o.write('  "%s", %d, %d, %d, %d, %d, %d, %d,\n' % (n, m.model_id, kind, m.nq, m.nu, m.nz, m.nth, m.nfric))
+    o.write("  %d, %s_ort1, %s_ort2, %s_ortr,\n" % (len(m.ort[0]), n, n, n))
+    o.write("  %d, %s_socoff, %s_soc1, %s_soc2, %s_socr,\n" % (len(m.soc), n, n, n, n))
+    o.write("  %d, %s_equr, %d, %s_bil, %d, %s_zq,\n" % (len(m.equr), n, len(m.bil), n, len(m.idx_zq), n))
+    o.write("  %s_zikind, %s_ziidx, %s_zival, %s_fric,\n" % (n, n, n, n))
+    o.write("  {%r, %r, %r, %d, %d, %r, %r, %r, %s},\n" % (
+        op["r_tol"], op["kappa_tol"], op["kappa_grad_tol"], op["max_iter"], op["max_ls"],
+        op["eps_min"], op["kappa_reg"], op["gamma_reg"], und))
+    o.write("  %s_r, %s_rz, %s_rth\n};\n\n" % (n, n, n))
+    return o.getvalue()
+
+
+# --------------------------------------------------------------------------------------
+# device flavour
+# --------------------------------------------------------------------------------------
+class _Elim:
+    """Static-order sparse Gaussian elimination on the structural pattern of rz."""
+
+    def __init__(self, nz: int, pattern: Sequence[Tuple[int, int]], order: Sequence[Tuple[int, int]]):
+        self.nz = nz
+        self.order = list(order)
+        pat = set(pattern)
+        rows = list(range(nz))
+        cols = list(range(nz))
+        self.slots = 0
+        self.fac_lines: List[str] = []
+        self.fwd: List[Tuple[int, List[Tuple[int, int]]]] = []       # (pr, [(row i, slot l)])
+        self.bwd: List[Tuple[int, int, int, List[Tuple[int, int]]]] = []  # (pr, pc, slot ip, [(col j, slot u)])
+        L = self.fac_lines
+        for (pr, pc) in self.order:
+            assert (pr, pc) in pat, ("structurally zero pivot", pr, pc)
+            assert pr in rows and pc in cols
+            rows.remove(pr)
+            cols.remove(pc)
+            ip = self._slot()
+            L.append("{ const T ip_ = T(1) / a_%d_%d; f.v[%d] = ip_;" % (pr, pc, ip))
+            fw = []
+            prow = [j for j in cols if (pr, j) in pat]
+            for i in rows:
+                if (i, pc) not in pat:
+                    continue
+                sl = self._slot()
+                L.append("  { const T l_ = a_%d_%d * ip_; f.v[%d] = l_;" % (i, pc, sl))
+                fw.append((i, sl))
+                for j in prow:
+                    if (i, j) in pat:
+                        L.append("    a_%d_%d -= l_ * a_%d_%d;" % (i, j, pr, j))
+                    else:
+                        L.append("    a_%d_%d = -(l_ * a_%d_%d);" % (i, j, pr, j))
+                        pat.add((i, j))
+                L.append("  }")
+            us = []
+            for j in prow:
+                sl = self._slot()
+                L.append("  f.v[%d] = a_%d_%d;" % (sl, pr, j))
+                us.append((j, sl))
+            L.append("}")
+            self.fwd.append((pr, fw))
+            self.bwd.append((pr, pc, ip, us))
+        self.tail_rows = rows
+        self.tail_cols = cols
+        self.m = len(rows)
+        self.tail_base = self.slots
+        self.slots += self.m * self.m
+        self.final_pattern = pat
+
+    def _slot(self):
+        s = self.slots
+        self.slots += 1
+        return s
+
+
+def emit_device(m: ModelSpec, d: Derived) -> str:
+    pr = _DevicePrinter()
+    n = m.name
+    o = io.StringIO()
+    o.write("// GENERATED by optimization_dynamics_amd.codegen (device flavour) -- do not edit.\n")
+    o.write("// Model %s: nz=%d ntheta=%d  (reference residual statement: see codegen/models.py)\n" % (n, m.nz, m.nth))
+    o.write("#pragma once\n#include \"../od_math.h\"\n\nnamespace od {\n\n")
+
+    sub = {s: sp.Symbol("z[%d]" % i) for i, s in enumerate(m.z)}
+    sub.update({s: sp.Symbol("th[%d]" % i) for i, s in enumerate(m.th)})
+
+    def S(e):
+        return e.subs(sub, simultaneous=True)
+
+    el = _Elim(m.nz, d.rz_nz, m.elim)
+    nnz = len(d.rz_nz)
+    nnzth = len(d.rth_nz)
+
+    def arr(name, xs, ty="int"):
+        xs = list(xs)
+        if not xs:
+            xs = [0]
+        return "  static constexpr %s %s[%d] = {%s};\n" % (ty, name, len(xs), ", ".join(str(x) for x in xs))
+
+    soc_flat_p, soc_flat_d, soc_off, socr_flat = [], [], [0], []
+    for (p, dd), rr in zip(m.soc, m.socri):
+        soc_flat_p += p
+        soc_flat_d += dd
+        socr_flat += rr
+        soc_off.append(len(soc_flat_p))
+    max_soc = max([len(p) for p, _ in m.soc], default=1)
+
+    o.write("struct Model_%s {\n" % n)
+    o.write("  static constexpr int ID = %d;\n" % m.model_id)
+    o.write("  static constexpr int KIND = %d;  // 0 mech (theta=[q0;q1;u;fric;h]), 1 rocket, 2 projection\n"
+            % {"mech": 0, "rocket": 1, "proj": 2}[m.kind])
+    o.write("  static constexpr int NQ = %d, NU = %d, NZ = %d, NTH = %d, NFRIC = %d;\n" % (m.nq, m.nu, m.nz, m.nth, m.nfric))
+    o.write("  static constexpr int NNZ = %d, NNZTH = %d, NGC = %d;\n" % (nnz, nnzth, len(d.grad_cols)))
+    o.write("  static constexpr int NORT = %d, NSOC = %d, MAXSOC = %d, NEQ = %d, NBIL = %d, NZQ = %d;\n"
+            % (len(m.ort[0]), len(m.soc), max_soc, len(m.equr), len(m.bil), len(m.idx_zq)))
+    o.write("  static constexpr bool REG_POSTHOC = %s;\n" % ("true" if d.reg_posthoc else "false"))
+    o.write("  static constexpr int NFACT = %d, MTAIL = %d, TAIL_BASE = %d;\n" % (el.slots, el.m, el.tail_base))
+    o.write(arr("ORT1", m.ort[0]) + arr("ORT2", m.ort[1]) + arr("ORTR", m.ortr))
+    o.write(arr("SOCOFF", soc_off) + arr("SOC1", soc_flat_p) + arr("SOC2", soc_flat_d) + arr("SOCR", socr_flat))
+    o.write(arr("EQUR", m.equr) + arr("BIL", m.bil) + arr("ZQ", m.idx_zq))
+    o.write(arr("KROWS", d.kappa_rows))
+    o.write("  static constexpr int NKROWS = %d;\n" % len(d.kappa_rows))
+    # posthoc clamp entries: (nnz slot, partner variable)
+    o.write("  static constexpr int NORTENT = %d;\n" % len(d.ort_entries))
+    o.write(arr("ORTENT_SLOT", [k for k, _ in d.ort_entries]) + arr("ORTENT_VAR", [v for _, v in d.ort_entries]))
+    zi_kind = [0 if isinstance(e, tuple) else 1 for e in m.z_init]
+    zi_idx = [e[1] if isinstance(e, tuple) else 0 for e in m.z_init]
+    zi_val = [0.0 if isinstance(e, tuple) else float(e) for e in m.z_init]
+    o.write(arr("ZI_KIND", zi_kind) + arr("ZI_IDX", zi_idx) + arr("ZI_VAL", [repr(v) for v in zi_val], "double"))
+    o.write(arr("FRIC_DEFAULT", [repr(float(v)) for v in (m.fric_default or [0.0])], "double"))
+    # rtheta sparse structure (row, column-position within grad cols)
+    o.write(arr("RTH_ROW", [i for i, _ in d.rth_nz]) + arr("RTH_COL", [d.grad_cols.index(j) for _, j in d.rth_nz]))
+    op = m.opts
+    o.write("  static constexpr double DEF_R_TOL = %r, DEF_KAPPA_EVAL = %r, DEF_KAPPA_GRAD = %r;\n"
+            % (op["r_tol"], op["kappa_tol"], op["kappa_grad_tol"]))
+    o.write("  static constexpr double DEF_EPS_MIN = %r, DEF_KAPPA_REG = %r, DEF_GAMMA_REG = %r;\n"
+            % (op["eps_min"], op["kappa_reg"], op["gamma_reg"]))
+    und = "1e300" if op["undercut"] == float("inf") else repr(float(op["undercut"]))
+    o.write("  static constexpr double DEF_UNDERCUT = %s;  // 1e300 stands for Inf\n" % und)
+    o.write("  static constexpr int DEF_MAX_ITER = %d, DEF_MAX_LS = %d;\n" % (op["max_iter"], op["max_ls"]))
+    o.write('  static constexpr const char* NAME = "%s";\n\n' % n)
+
+    def func(sig, exprs, outs_spec, prefix):
+        """outs_spec: list of (array name, index) aligned with exprs."""
+        o.write("  template <class T> OD_HD static inline void %s {\n" % sig)
+        lines, outs = _cse_block(exprs, pr, "T", prefix)
+        for ln in lines:
+            o.write("    " + ln + "\n")
+        for (an, idx), e in zip(outs_spec, outs):
+            o.write("    %s[%d] = %s;\n" % (an, idx, e))
+        o.write("  }\n\n")
+
+    r0 = [S(e) for e in d.r0]
+    rzv = [S(d.rz[i, j]) for (i, j) in d.rz_nz]
+    rthv = [S(d.rth[i, j]) for (i, j) in d.rth_nz]
+    func("eval_r(const T* z, const T* th, T* r)", r0, [("r", i) for i in range(m.nz)], "x")
+    func("eval_rz(const T* z, const T* th, T* a)", rzv, [("a", k) for k in range(nnz)], "x")
+    func("eval_r_rz(const T* z, const T* th, T* r, T* a)", r0 + rzv,
+         [("r", i) for i in range(m.nz)] + [("a", k) for k in range(nnz)], "x")
+    func("eval_rth(const T* z, const T* th, T* g)", rthv, [("g", k) for k in range(nnzth)], "x")
+
+    # ---- factor ----
+    o.write("  template <class T> struct Fact { T v[NFACT > 0 ? NFACT : 1]; int piv[MTAIL > 0 ? MTAIL : 1]; };\n\n")
+    o.write("  // statically ordered sparse elimination (%d pivots) + %dx%d runtime-pivoted dense tail\n"
+            % (len(m.elim), el.m, el.m))
+    o.write("  template <class T> OD_HD static inline bool factor(const T* a, Fact<T>& f) {\n")
+    for k, (i, j) in enumerate(d.rz_nz):
+        o.write("    T a_%d_%d = a[%d];\n" % (i, j, k))
+    fills = sorted(el.final_pattern - set(d.rz_nz))
+    for (i, j) in fills:
+        o.write("    T a_%d_%d;\n" % (i, j))
+    for ln in el.fac_lines:
+        o.write("    " + ln + "\n")
+    for ii, i in enumerate(el.tail_rows):
+        for jj, j in enumerate(el.tail_cols):
+            if (i, j) in el.final_pattern:
+                o.write("    f.v[%d] = a_%d_%d;\n" % (el.tail_base + ii + el.m * jj, i, j))
+            else:
+                o.write("    f.v[%d] = T(0);\n" % (el.tail_base + ii + el.m * jj))
+    if el.m > 0:
+        o.write("    return od_lu_factor<T, MTAIL>(&f.v[TAIL_BASE], f.piv);\n")
+    else:
+        o.write("    return true;\n")
+    o.write("  }\n\n")
+
+    # ---- solve ----
+    o.write("  // x = rz^{-1} b using the stored factors (b and x may alias)\n")
+    o.write("  template <class T> OD_HD static inline void solve(const Fact<T>& f, const T* b, T* x) {\n")
+    for i in range(m.nz):
+        o.write("    T y_%d = b[%d];\n" % (i, i))
+    for (prw, fw) in el.fwd:
+        for (i, sl) in fw:
+            o.write("    y_%d -= f.v[%d] * y_%d;\n" % (i, sl, prw))
+    if el.m > 0:
+        o.write("    T t_[MTAIL];\n")
+        for ii, i in enumerate(el.tail_rows):
+            o.write("    t_[%d] = y_%d;\n" % (ii, i))
+        o.write("    od_lu_solve<T, MTAIL>(&f.v[TAIL_BASE], f.piv, t_);\n")
+        for jj, j in enumerate(el.tail_cols):
+            o.write("    const T x_%d = t_[%d];\n" % (j, jj))
+    for (prw, pc, ip, us) in reversed(el.bwd):
+        terms = "".join(" - f.v[%d] * x_%d" % (sl, j) for (j, sl) in us)
+        o.write("    const T x_%d = (y_%d%s) * f.v[%d];\n" % (pc, prw, terms, ip))
+    for j in range(m.nz):
+        o.write("    x[%d] = x_%d;\n" % (j, j))
+    o.write("  }\n")
+    o.write("};\n\n}  // namespace od\n")
+    return o.getvalue()
+
+
+def stats(m: ModelSpec, d: Derived) -> Dict[str, int]:
+    return dict(
+        nz=m.nz, nth=m.nth, nnz_rz=len(d.rz_nz), nnz_rth=len(d.rth_nz),
+        ops_r=count_ops(list(d.r0)), ops_rz=count_ops([d.rz[i, j] for (i, j) in d.rz_nz]),
+        ops_r_rz=count_ops(list(d.r0) + [d.rz[i, j] for (i, j) in d.rz_nz]),
+        ops_rth=count_ops([d.rth[i, j] for (i, j) in d.rth_nz]),
+    )

@@ -1,0 +1,241 @@
+"""ctypes binding of the CPU oracle (oracle/ip_oracle.c) -- TEST INFRASTRUCTURE ONLY.
+
+Imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MODEL_IDS = {
+    "acrobot_impact": 0, "acrobot_nominal": 1, "cartpole_friction": 2, "cartpole_frictionless": 3,
+    "planar_push": 4, "rocket_dynamics": 5, "rocket_projection": 6, "hopper": 7,
+}
+
+
+class Opts(C.Structure):
+    _fields_ = [("r_tol", C.c_double), ("kappa_tol", C.c_double), ("kappa_grad_tol", C.c_double),
+                ("max_iter", C.c_int), ("max_ls", C.c_int),
+                ("eps_min", C.c_double), ("kappa_reg", C.c_double), ("gamma_reg", C.c_double),
+                ("undercut", C.c_double)]
+
+
+class Sim(C.Structure):
+    _fields_ = [("model_id", C.c_int), ("opts", Opts), ("h", C.c_double),
+                ("fric", C.c_double * 4), ("u_max", C.c_double)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libod_oracle.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE, "libod_oracle.so"] + (["-B"] if force else []),
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.od_oracle_model_name.restype = C.c_char_p
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def dims(model):
+    mid = MODEL_IDS[model] if isinstance(model, str) else model
+    v = [C.c_int() for _ in range(5)]
+    lib().od_oracle_model_dims(mid, *[C.byref(x) for x in v])
+    return dict(zip(["nq", "nu", "nz", "nth", "nfric"], [x.value for x in v]))
+
+
+def make_sim(model, h, **over):
+    s = Sim()
+    lib().od_oracle_default_sim(MODEL_IDS[model], C.c_double(h), C.byref(s))
+    for k, v in over.items():
+        if k == "friction":
+            for i, f in enumerate(v):
+                s.fric[i] = f
+        elif k == "u_max":
+            s.u_max = v
+        else:
+            setattr(s.opts, k, v)
+    return s
+
+
+def eval_r(model, z, th, kappa=0.0):
+    d = dims(model)
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    th = np.ascontiguousarray(th, dtype=np.float64)
+    r = np.zeros(d["nz"])
+    lib().od_oracle_eval_r(MODEL_IDS[model], _p(z), _p(th), C.c_double(kappa), _p(r))
+    return r
+
+
+def eval_rz(model, z, th):
+    d = dims(model)
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    th = np.ascontiguousarray(th, dtype=np.float64)
+    out = np.zeros(d["nz"] * d["nz"])
+    lib().od_oracle_eval_rz(MODEL_IDS[model], _p(z), _p(th), _p(out))
+    return out.reshape(d["nz"], d["nz"], order="F")
+
+
+def eval_rth(model, z, th):
+    d = dims(model)
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    th = np.ascontiguousarray(th, dtype=np.float64)
+    out = np.zeros(d["nz"] * d["nth"])
+    lib().od_oracle_eval_rth(MODEL_IDS[model], _p(z), _p(th), _p(out))
+    return out.reshape(d["nz"], d["nth"], order="F")
+
+
+def ip_solve(model, z0, th, kappa_tol=None, diff_sol=False, opts=None):
+    """raw interior_point_solve!: returns (status, z, dz or None, iters)"""
+    d = dims(model)
+    s = make_sim(model, 0.0)
+    o = opts if opts is not None else s.opts
+    z = np.array(z0, dtype=np.float64)
+    th = np.ascontiguousarray(th, dtype=np.float64)
+    dz = np.zeros(d["nz"] * d["nth"]) if diff_sol else None
+    it = C.c_int()
+    kt = o.kappa_tol if kappa_tol is None else kappa_tol
+    st = lib().od_oracle_ip_solve(MODEL_IDS[model], C.byref(o), C.c_double(kt), int(diff_sol), _p(z), _p(th), _p(dz), C.byref(it))
+    return st, z, (dz.reshape(d["nz"], d["nth"], order="F") if diff_sol else None), it.value
+
+
+def f(sim, x, u):
+    d = dims(sim.model_id)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    out = np.zeros(2 * d["nq"])
+    it = C.c_int()
+    st = lib().od_oracle_f(C.byref(sim), _p(x), _p(u), _p(out), C.byref(it))
+    return st, out, it.value
+
+
+def fx(sim, x, u):
+    d = dims(sim.model_id)
+    n = 2 * d["nq"]
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    out = np.zeros(n * n)
+    it = C.c_int()
+    st = lib().od_oracle_fx(C.byref(sim), _p(x), _p(u), _p(out), C.byref(it))
+    return st, out.reshape(n, n, order="F"), it.value
+
+
+def fu(sim, x, u):
+    d = dims(sim.model_id)
+    n = 2 * d["nq"]
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    out = np.zeros(n * d["nu"])
+    it = C.c_int()
+    st = lib().od_oracle_fu(C.byref(sim), _p(x), _p(u), _p(out), C.byref(it))
+    return st, out.reshape(n, d["nu"], order="F"), it.value
+
+
+def step_full(sim, x, u, kappa_tol, diff_sol=True):
+    d = dims(sim.model_id)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    z = np.zeros(d["nz"])
+    dz = np.zeros(d["nz"] * d["nth"])
+    it = C.c_int()
+    st = lib().od_oracle_step_full(C.byref(sim), C.c_double(kappa_tol), int(diff_sol), _p(x), _p(u), _p(z), _p(dz), C.byref(it))
+    return st, z, dz.reshape(d["nz"], d["nth"], order="F"), it.value
+
+
+def ls_update(fz, feta, eta, theta0=None):
+    """src/ls.jl update!: feta (ny x N), eta (nzb x N); returns (theta as ny x nzb, newton iterations)"""
+    feta = np.asfortranarray(feta, dtype=np.float64)
+    eta = np.asfortranarray(eta, dtype=np.float64)
+    fz = np.ascontiguousarray(fz, dtype=np.float64)
+    ny, N = feta.shape
+    nzb = eta.shape[0]
+    th = np.zeros(ny * nzb) if theta0 is None else np.array(theta0, dtype=np.float64).reshape(-1, order="F")
+    it = lib().od_oracle_ls_update(N, ny, nzb, _p(fz), _p(feta.reshape(-1, order="F")), _p(eta.reshape(-1, order="F")), _p(th))
+    return th.reshape(ny, nzb, order="F"), it
+
+
+def gradient_bundle(sim, eta, q1, q2, u1, theta0=None):
+    d = dims(sim.model_id)
+    nq, nu = d["nq"], d["nu"]
+    nzb = 2 * nq + nu
+    eta = np.asfortranarray(eta, dtype=np.float64)
+    N = eta.shape[1]
+    th = np.zeros(nq * nzb) if theta0 is None else np.array(theta0, dtype=np.float64).reshape(-1, order="F")
+    out = np.zeros(nq * nzb)
+    q1 = np.ascontiguousarray(q1, dtype=np.float64)
+    q2 = np.ascontiguousarray(q2, dtype=np.float64)
+    u1 = np.ascontiguousarray(u1, dtype=np.float64)
+    ok = lib().od_oracle_gradient_bundle(C.byref(sim), N, _p(eta.reshape(-1, order="F")), _p(q1), _p(q2), _p(u1), _p(th), _p(out))
+    return ok, out.reshape(nq, nzb, order="F")
+
+
+def rocket(h, x, u, diff_sol=True):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    y = np.zeros(12)
+    dz = np.zeros(12 * 16)
+    it = C.c_int()
+    st = lib().od_oracle_rocket(C.c_double(h), _p(x), _p(u), int(diff_sol), _p(y), _p(dz), C.byref(it))
+    return st, y, dz.reshape(12, 16, order="F"), it.value
+
+
+def soc_projection(u_max, u, diff_sol=True):
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    z = np.zeros(10)
+    dz = np.zeros(40)
+    it = C.c_int()
+    st = lib().od_oracle_soc_projection(C.c_double(u_max), _p(u), int(diff_sol), _p(z), _p(dz), C.byref(it))
+    return st, z, dz.reshape(10, 4, order="F"), it.value
+
+
+def rocket_proj(h, u_max, x, u):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    y = np.zeros(12)
+    dx = np.zeros(144)
+    du = np.zeros(36)
+    ok = lib().od_oracle_rocket_proj(C.c_double(h), C.c_double(u_max), _p(x), _p(u), _p(y), _p(dx), _p(du))
+    return ok, y, dx.reshape(12, 12, order="F"), du.reshape(12, 3, order="F")
+
+
+def step_grad_batch(sim, X, U):
+    """X: (2nq, B), U: (nu, B) -> d (2nq,B), dx (2nq,2nq,B), du (2nq,nu,B), nbad"""
+    d = dims(sim.model_id)
+    n, nu = 2 * d["nq"], d["nu"]
+    X = np.asfortranarray(X, dtype=np.float64)
+    U = np.asfortranarray(U, dtype=np.float64)
+    B = X.shape[1]
+    D = np.zeros(n * B)
+    DX = np.zeros(n * n * B)
+    DU = np.zeros(n * nu * B)
+    bad = lib().od_oracle_step_grad_batch(C.byref(sim), B, _p(X.reshape(-1, order="F")), _p(U.reshape(-1, order="F")), _p(D), _p(DX), _p(DU), 0)
+    return D.reshape(n, B, order="F"), DX.reshape(n, n, B, order="F"), DU.reshape(n, nu, B, order="F"), bad
+
+
+def rollout(sim, x1, U, grads=True):
+    """x1: (2nq,B); U: (nu,T,B) -> X (2nq,T+1,B), A (2nq,2nq,T,B), Bm (2nq,nu,T,B), nbad"""
+    d = dims(sim.model_id)
+    n, nu = 2 * d["nq"], d["nu"]
+    x1 = np.asfortranarray(x1, dtype=np.float64)
+    U = np.asfortranarray(U, dtype=np.float64)
+    T, B = U.shape[1], U.shape[2]
+    X = np.zeros(n * (T + 1) * B)
+    A = np.zeros(n * n * T * B) if grads else None
+    Bm = np.zeros(n * nu * T * B) if grads else None
+    bad = lib().od_oracle_rollout(C.byref(sim), B, T, _p(x1.reshape(-1, order="F")), _p(U.reshape(-1, order="F")), _p(X), _p(A), _p(Bm))
+    X = X.reshape(n, T + 1, B, order="F")
+    if grads:
+        return X, A.reshape(n, n, T, B, order="F"), Bm.reshape(n, nu, T, B, order="F"), bad
+    return X, None, None, bad
