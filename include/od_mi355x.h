@@ -1,0 +1,144 @@
+/*
+ * od_mi355x.h -- C ABI of the MI355X-native batched implicit-dynamics engine (libod_mi355x.so).
+ *
+ * Drop-in boundary for the hot path of thowell/optimization_dynamics: the per-timestep interior-
+ * point solve + implicit-function gradient behind the iLQR dynamics callbacks.  Each entry point
+ * names the reference interface it replaces (paths relative to the reference repository).
+ * The reference is pure Julia; the binding a maintainer would add is a `ccall` shim
+ * (julia/OptimizationDynamicsMI355X.jl).  tests/ bind the same symbols via ctypes.
+ *
+ * Conventions
+ *  - All batched entry points take DEVICE pointers and are asynchronous on the handle's HIP stream
+ *    (od_set_stream); the *_host entry points take host pointers, copy, launch and synchronise.
+ *  - Return value: 0 on success, negative od_error otherwise; od_last_error() gives the message.
+ *    Solver non-convergence is NOT an error (the reference only returns a Bool and still copies the
+ *    result out, src/models/rocket/dynamics.jl:178-186): it is reported per problem in `status`.
+ *  - Per-problem arrays are addressed as element e of problem k:
+ *      OD_LAYOUT_BATCH_MINOR (default):  base[e * K + k]   (K = number of problems in the array;
+ *                                         lanes of a wavefront touch consecutive addresses)
+ *      OD_LAYOUT_BATCH_MAJOR:            base[k * E + e]   (E = elements per problem; this is a
+ *                                         Julia/Fortran  E x K  column-major matrix)
+ *    Matrices per problem (dx, du, dz) are column-major inside their E elements, like the reference's
+ *    Julia matrices.  For rollouts the problem index of knot t of trajectory b is k = t*B + b.
+ *  - Element type is double for OD_F64 handles and float for OD_F32 handles.
+ *  - status bits: 1 = state converged to (r_tol, kappa_eval_tol), 2 = gradient iterate converged to
+ *    (r_tol, kappa_grad_tol), 4 = all KKT factorisations were non-singular.
+ */
+#ifndef OD_MI355X_H
+#define OD_MI355X_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct od_handle_s* od_handle;
+
+enum od_error {
+  OD_OK = 0, OD_ERR_INVALID = -1, OD_ERR_UNSUPPORTED = -2, OD_ERR_HIP = -3, OD_ERR_NO_DEVICE = -4
+};
+
+/* model ids: src/models/<model>; hopper is RoboDojo.hopper (examples/hopper.jl:14) */
+enum od_model {
+  OD_ACROBOT_IMPACT = 0, OD_ACROBOT_NOMINAL = 1, OD_CARTPOLE_FRICTION = 2, OD_CARTPOLE_FRICTIONLESS = 3,
+  OD_PLANAR_PUSH = 4, OD_ROCKET_DYNAMICS = 5, OD_ROCKET_PROJECTION = 6, OD_HOPPER = 7, OD_NUM_MODELS = 8
+};
+enum od_dtype { OD_F64 = 0, OD_F32 = 1 };
+enum od_layout { OD_LAYOUT_BATCH_MINOR = 0, OD_LAYOUT_BATCH_MAJOR = 1 };
+enum od_status_bits { OD_STATUS_EVAL_OK = 1, OD_STATUS_GRAD_OK = 2, OD_STATUS_FACTOR_OK = 4 };
+
+/* InteriorPointOptions as set by get_simulator (src/dynamics.jl:25-33) and RocketInfo
+ * (src/models/rocket/dynamics.jl:21-27,77-86).  kappa_eval_tol / kappa_grad_tol are the two
+ * ImplicitDynamics keywords (src/dynamics.jl:51-53).  undercut = INFINITY is allowed. */
+typedef struct {
+  double r_tol, kappa_eval_tol, kappa_grad_tol;
+  int max_iter, max_ls;
+  double eps_min, kappa_reg, gamma_reg, undercut;
+} od_options;
+
+int od_version(void);
+const char* od_last_error(void);
+
+/* model table: dimensions of src/models/<model> (nq, nu, nz = num_var, ntheta = num_data, nfric) */
+int od_model_dims(int model, int* nq, int* nu, int* nz, int* ntheta, int* nfric);
+const char* od_model_name(int model);
+/* option preset of the example that uses the model (examples/<model>.jl) */
+int od_default_options(int model, od_options* out);
+
+/* ImplicitDynamics(model, h, r, rz, rtheta; r_tol, kappa_eval_tol, kappa_grad_tol, ...)
+ * (src/dynamics.jl:51-79): one handle = eval_sim + grad_sim of one model.  opts may be NULL. */
+int od_create(int model, int dtype, const od_options* opts, double h, od_handle* out);
+int od_destroy(od_handle h);
+int od_set_options(od_handle h, const od_options* opts);
+int od_get_options(od_handle h, od_options* out);
+int od_set_timestep(od_handle h, double dt);
+/* friction_coefficients(model) (e.g. cartpole_friction.friction .= [0.35; 0.35], examples/cartpole.jl:21) */
+int od_set_friction(od_handle h, const double* mu, int n);
+/* RocketInfo.u_max (src/models/rocket/dynamics.jl:8) */
+int od_set_u_max(od_handle h, double u_max);
+int od_set_layout(od_handle h, int layout);
+int od_set_stream(od_handle h, void* hip_stream);
+int od_synchronize(od_handle h);
+
+/* f (src/dynamics.jl:81-94) for B knots: d = [q2; q3].  x: 2nq, u: nu, d: 2nq per problem.
+ * status, iters (2 ints per problem: iterations to kappa_eval / kappa_grad) may be NULL. */
+int od_step(od_handle h, long B, const void* x, const void* u, void* d, int* status, int* iters);
+
+/* f + fx + fu (src/dynamics.jl:81-128) in one solve per knot.  dx: 2nq x 2nq, du: 2nq x nu per
+ * problem, every entry written (the reference writes 3 blocks into a caller-zeroed matrix).
+ * Any of d, dx, du may be NULL. */
+int od_step_grad(od_handle h, long B, const void* x, const void* u, void* d, void* dx, void* du,
+                 int* status, int* iters);
+
+/* same solve, compact outputs: q3 (nq) and dq3 = d q3 / d(q1, q2, u1): nq x (2nq+nu) per problem
+ * (= grad.dq3dq1[1], dq3dq2[1], dq3du1[1] of the reference's grad_sim, src/dynamics.jl:110-111,125) */
+int od_step_grad_compact(od_handle h, long B, const void* x, const void* u, void* q3, void* dq3,
+                         int* status, int* iters);
+
+/* iLQR.rollout through f plus the derivative sweep through fx, fu (examples/acrobot.jl:92 and the
+ * solver's per-knot fx/fu calls) for B trajectories of T steps, time recursion on device.
+ * x1: 2nq per trajectory; U: nu per knot (T*B knots); X: 2nq per slot ((T+1)*B slots, slot 0 = x1);
+ * A: 2nq x 2nq per knot; Bm: 2nq x nu per knot.  A, Bm, status (T*B), iters (2*T*B) may be NULL. */
+int od_rollout(od_handle h, long B, int T, const void* x1, const void* U, void* X, void* A, void* Bm,
+               int* status, int* iters);
+
+/* gradient! (src/gradient_bundle.jl:87-104) for B knots: N+1 eval-simulator steps per knot with the
+ * caller's perturbations eta ((2nq+nu) x N col-major, shared by all knots; the reference draws them
+ * in the GradientBundle constructor :49-54) followed by the least-squares fit of src/ls.jl:44-60.
+ * dz: nq x (2nq+nu) per knot.  workspace: device scratch of od_bundle_workspace_bytes(). */
+size_t od_bundle_workspace_bytes(od_handle h, long B, int N);
+int od_bundle_grad(od_handle h, long B, int N, const void* x, const void* u, const void* eta,
+                   void* dz, void* workspace, size_t workspace_bytes, int* status);
+
+/* LeastSquares update! (src/ls.jl:44-60) alone, for B independent fits: minimise
+ * sum_i |f_eta_i - f_z - M eta_i|^2 over M (ny x nzb).  feta: ny per sample, (N+1)*B samples in
+ * BATCH_MINOR order, sample index b*(N+1)+i with i = 0 the unperturbed f_z; eta: nzb x N col-major;
+ * M: ny x nzb per fit (handle layout).  ny, nzb <= 24. */
+int od_ls_fit(od_handle h, long B, int N, int ny, int nzb, const void* eta, const void* feta, void* M,
+              int* status);
+
+/* interior_point_solve!(ip) on caller-provided z0, theta (src/models/rocket/dynamics.jl:109,178):
+ * z: nz per problem; dz: nzq x ngc per problem (rows = solution block, cols = leading theta
+ * columns, see od_raw_grad_dims); dz may be NULL (diff_sol = false). */
+int od_raw_grad_dims(int model, int* nzq, int* ngc);
+int od_ip_solve(od_handle h, long B, const void* z0, const void* theta, void* z, void* dz,
+                int* status, int* iters);
+
+/* f_rocket / fx_rocket / fu_rocket (project = 0, src/models/rocket/dynamics.jl:101-164) and
+ * f_rocket_proj / fx_rocket_proj / fu_rocket_proj (project = 1, :215-268) on an
+ * OD_ROCKET_DYNAMICS handle.  x: 12, u: 3, y: 12, dx: 12x12, du: 12x3, uproj: 3 per problem.
+ * status bits 1,2,4 = dynamics solve; 16, 32 = projection solve state / gradient converged. */
+int od_rocket(od_handle h, long B, int project, const void* x, const void* u, void* y, void* dx,
+              void* du, void* uproj, int* status);
+
+/* host-pointer scalar path (B = 1), the plumbing config: reference signatures f(d,model,x,u,w),
+ * fx(dx,...), fu(du,...) (src/dynamics.jl:81,96,116).  Column-major, every entry written. */
+int od_f_host(od_handle h, const double* x, const double* u, double* d);
+int od_fx_host(od_handle h, const double* x, const double* u, double* dx);
+int od_fu_host(od_handle h, const double* x, const double* u, double* du);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OD_MI355X_H */

@@ -1,0 +1,112 @@
+"""ctypes binding of libod_mi355x.so (include/od_mi355x.h).
+
+There is NO fallback: if the HIP library has not been built (``python -c 'import __graft_entry__ as g;
+g.build()'`` or ``make -C optimization_dynamics_amd/csrc``) loading fails loudly, and ``od_create``
+fails with OD_ERR_NO_DEVICE when no MI355X is visible.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_PATH = os.path.join(_HERE, "libod_mi355x.so")
+
+MODEL_IDS = {
+    "acrobot_impact": 0, "acrobot_nominal": 1, "cartpole_friction": 2, "cartpole_frictionless": 3,
+    "planar_push": 4, "rocket_dynamics": 5, "rocket_projection": 6, "hopper": 7,
+}
+OD_F64, OD_F32 = 0, 1
+LAYOUT_BATCH_MINOR, LAYOUT_BATCH_MAJOR = 0, 1
+STATUS_EVAL_OK, STATUS_GRAD_OK, STATUS_FACTOR_OK = 1, 2, 4
+
+
+class Options(C.Structure):
+    """od_options == InteriorPointOptions preset (src/dynamics.jl:25-33)."""
+    _fields_ = [("r_tol", C.c_double), ("kappa_eval_tol", C.c_double), ("kappa_grad_tol", C.c_double),
+                ("max_iter", C.c_int), ("max_ls", C.c_int),
+                ("eps_min", C.c_double), ("kappa_reg", C.c_double), ("gamma_reg", C.c_double),
+                ("undercut", C.c_double)]
+
+
+class ODError(RuntimeError):
+    pass
+
+
+_VP = C.c_void_p
+_IP = C.c_void_p   # int* passed as raw address (0 = NULL)
+
+# every symbol declared in include/od_mi355x.h: (restype, argtypes)
+SIGNATURES = {
+    "od_version": (C.c_int, []),
+    "od_last_error": (C.c_char_p, []),
+    "od_model_dims": (C.c_int, [C.c_int] + [C.POINTER(C.c_int)] * 5),
+    "od_model_name": (C.c_char_p, [C.c_int]),
+    "od_default_options": (C.c_int, [C.c_int, C.POINTER(Options)]),
+    "od_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(Options), C.c_double, C.POINTER(_VP)]),
+    "od_destroy": (C.c_int, [_VP]),
+    "od_set_options": (C.c_int, [_VP, C.POINTER(Options)]),
+    "od_get_options": (C.c_int, [_VP, C.POINTER(Options)]),
+    "od_set_timestep": (C.c_int, [_VP, C.c_double]),
+    "od_set_friction": (C.c_int, [_VP, C.POINTER(C.c_double), C.c_int]),
+    "od_set_u_max": (C.c_int, [_VP, C.c_double]),
+    "od_set_layout": (C.c_int, [_VP, C.c_int]),
+    "od_set_stream": (C.c_int, [_VP, _VP]),
+    "od_synchronize": (C.c_int, [_VP]),
+    "od_step": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _IP, _IP]),
+    "od_step_grad": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _VP, _VP, _IP, _IP]),
+    "od_step_grad_compact": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _VP, _IP, _IP]),
+    "od_rollout": (C.c_int, [_VP, C.c_long, C.c_int, _VP, _VP, _VP, _VP, _VP, _IP, _IP]),
+    "od_bundle_workspace_bytes": (C.c_size_t, [_VP, C.c_long, C.c_int]),
+    "od_bundle_grad": (C.c_int, [_VP, C.c_long, C.c_int, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _IP]),
+    "od_ls_fit": (C.c_int, [_VP, C.c_long, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _IP]),
+    "od_raw_grad_dims": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "od_ip_solve": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _VP, _IP, _IP]),
+    "od_rocket": (C.c_int, [_VP, C.c_long, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _IP]),
+    "od_f_host": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "od_fx_host": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "od_fu_host": (C.c_int, [_VP, _VP, _VP, _VP]),
+}
+
+
+class Library:
+    """A loaded libod_mi355x.so with typed entry points; errors raise ODError."""
+
+    def __init__(self, path=None):
+        self.path = path or DEFAULT_PATH
+        if not os.path.exists(self.path):
+            raise ODError(
+                "HIP extension %s is missing: build it with `make -C %s -j8` (hipcc, gfx950). "
+                "There is no CPU fallback." % (self.path, os.path.join(_HERE, "csrc")))
+        self.cdll = C.CDLL(self.path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self.cdll, name)   # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+
+    def check(self, rc):
+        if rc != 0:
+            raise ODError("libod_mi355x error %d: %s" % (rc, self.cdll.od_last_error().decode()))
+
+    def model_dims(self, model):
+        v = [C.c_int() for _ in range(5)]
+        self.check(self.cdll.od_model_dims(MODEL_IDS[model], *[C.byref(x) for x in v]))
+        return dict(zip(["nq", "nu", "nz", "ntheta", "nfric"], [x.value for x in v]))
+
+    def raw_grad_dims(self, model):
+        a, b = C.c_int(), C.c_int()
+        self.check(self.cdll.od_raw_grad_dims(MODEL_IDS[model], C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def default_options(self, model):
+        o = Options()
+        self.check(self.cdll.od_default_options(MODEL_IDS[model], C.byref(o)))
+        return o
+
+
+_default = None
+
+
+def default_library():
+    global _default
+    if _default is None:
+        _default = Library()
+    return _default

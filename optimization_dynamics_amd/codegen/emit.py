@@ -228,18 +228,41 @@ def emit_oracle_table(m: ModelSpec) -> str:
 # device flavour
 # --------------------------------------------------------------------------------------
 class _Elim:
-    """Static-order sparse Gaussian elimination on the structural pattern of rz."""
+    """Static-order sparse Gaussian elimination on the structural pattern of rz, preceded by
+    runtime row/column role swaps for the second-order-cone blocks, followed by a dense tail."""
 
-    def __init__(self, nz: int, pattern: Sequence[Tuple[int, int]], order: Sequence[Tuple[int, int]]):
+    def __init__(self, nz, pattern, order, floor_pivots=(), swaps=()):
         self.nz = nz
         self.order = list(order)
+        self.swaps = list(swaps)
         pat = set(pattern)
+        self.init_zero = set()          # entries that exist only because of a swap union
+        self.swap_lines: List[str] = []
+        S = self.swap_lines
+        for k, ((ra, rb), (ca, cb)) in enumerate(self.swaps):
+            assert (ra, cb) in pat and (rb, ca) in pat
+            S.append("const bool sw%d = od_abs(a_%d_%d) > od_abs(a_%d_%d); f.sw[%d] = sw%d;" % (k, ra, cb, rb, ca, k, k))
+            cols = sorted({j for (i, j) in pat if i in (ra, rb)})
+            for j in cols:
+                for i in (ra, rb):
+                    if (i, j) not in pat:
+                        pat.add((i, j)); self.init_zero.add((i, j))
+                S.append("{ const T u_ = a_%d_%d, w_ = a_%d_%d; a_%d_%d = sw%d ? w_ : u_; a_%d_%d = sw%d ? u_ : w_; }"
+                         % (ra, j, rb, j, ra, j, k, rb, j, k))
+            rows = sorted({i for (i, j) in pat if j in (ca, cb)})
+            for i in rows:
+                for j in (ca, cb):
+                    if (i, j) not in pat:
+                        pat.add((i, j)); self.init_zero.add((i, j))
+                S.append("{ const T u_ = a_%d_%d, w_ = a_%d_%d; a_%d_%d = sw%d ? w_ : u_; a_%d_%d = sw%d ? u_ : w_; }"
+                         % (i, ca, i, cb, i, ca, k, i, cb, k))
+        self.pattern0 = set(pat)
         rows = list(range(nz))
         cols = list(range(nz))
         self.slots = 0
         self.fac_lines: List[str] = []
-        self.fwd: List[Tuple[int, List[Tuple[int, int]]]] = []       # (pr, [(row i, slot l)])
-        self.bwd: List[Tuple[int, int, int, List[Tuple[int, int]]]] = []  # (pr, pc, slot ip, [(col j, slot u)])
+        self.fwd = []   # (pr, [(row i, slot l)])
+        self.bwd = []   # (pr, pc, slot ip, [(col j, slot u)])
         L = self.fac_lines
         for (pr, pc) in self.order:
             assert (pr, pc) in pat, ("structurally zero pivot", pr, pc)
@@ -247,7 +270,10 @@ class _Elim:
             rows.remove(pr)
             cols.remove(pc)
             ip = self._slot()
-            L.append("{ const T ip_ = T(1) / a_%d_%d; f.v[%d] = ip_;" % (pr, pc, ip))
+            if (pr, pc) in floor_pivots:
+                L.append("{ const T ip_ = T(1) / od_max(a_%d_%d, T(OD_PIVOT_FLOOR)); f.v[%d] = ip_;" % (pr, pc, ip))
+            else:
+                L.append("{ const T ip_ = T(1) / a_%d_%d; f.v[%d] = ip_;" % (pr, pc, ip))
             fw = []
             prow = [j for j in cols if (pr, j) in pat]
             for i in rows:
@@ -298,7 +324,7 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
     def S(e):
         return e.subs(sub, simultaneous=True)
 
-    el = _Elim(m.nz, d.rz_nz, m.elim)
+    el = _Elim(m.nz, d.rz_nz, m.elim, set(m.floor_pivots), m.swaps)
     nnz = len(d.rz_nz)
     nnzth = len(d.rth_nz)
 
@@ -325,7 +351,7 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
     o.write("  static constexpr int NORT = %d, NSOC = %d, MAXSOC = %d, NEQ = %d, NBIL = %d, NZQ = %d;\n"
             % (len(m.ort[0]), len(m.soc), max_soc, len(m.equr), len(m.bil), len(m.idx_zq)))
     o.write("  static constexpr bool REG_POSTHOC = %s;\n" % ("true" if d.reg_posthoc else "false"))
-    o.write("  static constexpr int NFACT = %d, MTAIL = %d, TAIL_BASE = %d;\n" % (el.slots, el.m, el.tail_base))
+    o.write("  static constexpr int NFACT = %d, MTAIL = %d, TAIL_BASE = %d, NSWAP = %d;\n" % (el.slots, el.m, el.tail_base, len(el.swaps)))
     o.write(arr("ORT1", m.ort[0]) + arr("ORT2", m.ort[1]) + arr("ORTR", m.ortr))
     o.write(arr("SOCOFF", soc_off) + arr("SOC1", soc_flat_p) + arr("SOC2", soc_flat_d) + arr("SOCR", socr_flat))
     o.write(arr("EQUR", m.equr) + arr("BIL", m.bil) + arr("ZQ", m.idx_zq))
@@ -353,7 +379,7 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
 
     def func(sig, exprs, outs_spec, prefix):
         """outs_spec: list of (array name, index) aligned with exprs."""
-        o.write("  template <class T> OD_HD static inline void %s {\n" % sig)
+        o.write("  template <class T> OD_HD static void %s {\n" % sig)
         lines, outs = _cse_block(exprs, pr, "T", prefix)
         for ln in lines:
             o.write("    " + ln + "\n")
@@ -371,15 +397,20 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
     func("eval_rth(const T* z, const T* th, T* g)", rthv, [("g", k) for k in range(nnzth)], "x")
 
     # ---- factor ----
-    o.write("  template <class T> struct Fact { T v[NFACT > 0 ? NFACT : 1]; int piv[MTAIL > 0 ? MTAIL : 1]; };\n\n")
+    o.write("  template <class T> struct Fact { T v[NFACT > 0 ? NFACT : 1]; int piv[MTAIL > 0 ? MTAIL : 1]; bool sw[NSWAP > 0 ? NSWAP : 1]; };\n\n")
     o.write("  // statically ordered sparse elimination (%d pivots) + %dx%d runtime-pivoted dense tail\n"
             % (len(m.elim), el.m, el.m))
-    o.write("  template <class T> OD_HD static inline bool factor(const T* a, Fact<T>& f) {\n")
+    o.write("  template <class T> OD_HD static bool factor(const T* a, Fact<T>& f) {\n")
     for k, (i, j) in enumerate(d.rz_nz):
         o.write("    T a_%d_%d = a[%d];\n" % (i, j, k))
     fills = sorted(el.final_pattern - set(d.rz_nz))
     for (i, j) in fills:
-        o.write("    T a_%d_%d;\n" % (i, j))
+        if (i, j) in el.init_zero:
+            o.write("    T a_%d_%d = T(0);\n" % (i, j))
+        else:
+            o.write("    T a_%d_%d;\n" % (i, j))
+    for ln in el.swap_lines:
+        o.write("    " + ln + "\n")
     for ln in el.fac_lines:
         o.write("    " + ln + "\n")
     for ii, i in enumerate(el.tail_rows):
@@ -396,9 +427,11 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
 
     # ---- solve ----
     o.write("  // x = rz^{-1} b using the stored factors (b and x may alias)\n")
-    o.write("  template <class T> OD_HD static inline void solve(const Fact<T>& f, const T* b, T* x) {\n")
+    o.write("  template <class T> OD_HD static void solve(const Fact<T>& f, const T* b, T* x) {\n")
     for i in range(m.nz):
         o.write("    T y_%d = b[%d];\n" % (i, i))
+    for k, ((ra, rb), (ca, cb)) in enumerate(el.swaps):
+        o.write("    { const T u_ = y_%d, w_ = y_%d; y_%d = f.sw[%d] ? w_ : u_; y_%d = f.sw[%d] ? u_ : w_; }\n" % (ra, rb, ra, k, rb, k))
     for (prw, fw) in el.fwd:
         for (i, sl) in fw:
             o.write("    y_%d -= f.v[%d] * y_%d;\n" % (i, sl, prw))
@@ -412,8 +445,15 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
     for (prw, pc, ip, us) in reversed(el.bwd):
         terms = "".join(" - f.v[%d] * x_%d" % (sl, j) for (j, sl) in us)
         o.write("    const T x_%d = (y_%d%s) * f.v[%d];\n" % (pc, prw, terms, ip))
+    swapped = {}
+    for k, ((ra, rb), (ca, cb)) in enumerate(el.swaps):
+        swapped[ca] = (cb, k)
+        swapped[cb] = (ca, k)
     for j in range(m.nz):
-        o.write("    x[%d] = x_%d;\n" % (j, j))
+        if j in swapped:
+            o.write("    x[%d] = f.sw[%d] ? x_%d : x_%d;\n" % (j, swapped[j][1], swapped[j][0], j))
+        else:
+            o.write("    x[%d] = x_%d;\n" % (j, j))
     o.write("  }\n")
     o.write("};\n\n}  // namespace od\n")
     return o.getvalue()

@@ -53,6 +53,12 @@ class ModelSpec:
     idx_zq: List[int] = field(default_factory=list)
     # device elimination order: list of (row, col) static pivots
     elim: List[Tuple[int, int]] = field(default_factory=list)
+    # static pivots whose value is a strictly positive cone variable that may underflow towards 0
+    # (orthant slack): floored at OD_PIVOT_FLOOR in the factorisation
+    floor_pivots: List[Tuple[int, int]] = field(default_factory=list)
+    # runtime role swaps for second-order-cone blocks: ((row_a,row_b),(col_a,col_b)); rows/cols are
+    # exchanged when |A[row_a,col_b]| > |A[row_b,col_a]| (psi vs s_psi: sticking vs sliding mode)
+    swaps: List[Tuple[Tuple[int, int], Tuple[int, int]]] = field(default_factory=list)
     # default solver options (reference src/dynamics.jl:25-33 etc.)
     opts: Dict[str, float] = field(default_factory=dict)
     notes: str = ""
@@ -149,7 +155,7 @@ def acrobot_impact() -> ModelSpec:
         ort=([2, 3], [4, 5]), soc=[], equr=[0, 1, 2, 3], ortr=[4, 5], socri=[], bil=[4, 5],
         z_init=[("q", 0), ("q", 1), 1.0, 1.0, 1.0, 1.0],                   # :34-38
         kind="mech", nfric=0, idx_zq=[0, 1],
-        elim=[(2, 4), (3, 5), (4, 2), (5, 3)],
+        elim=[(2, 4), (3, 5), (4, 2), (5, 3)], floor_pivots=[(4, 2), (5, 3)],
         opts=dict(IP_DEFAULT, kappa_tol=1e-4, kappa_grad_tol=1e-3),       # examples/acrobot.jl:15-23
     )
 
@@ -221,8 +227,10 @@ def cartpole_friction() -> ModelSpec:
         z_init=[("q", 0), ("q", 1), 1.0, 1.0, 0.1, 0.1, 1.0, 1.0, 0.1, 0.1],   # :36-42
         kind="mech", nfric=2, fric_default=[0.1, 0.1], idx_zq=[0, 1],
         # rows: 2: sb0-vT1 (pivot sb0=z8), 3: psi0-.. (pivot psi0=z2), 4: sb1 (z9), 5: psi1 (z3)
-        # cone rows 6,7 / 8,9: pivot second row on b (coef spsi), first on spsi (coef psi)
-        elim=[(2, 8), (4, 9), (3, 2), (5, 3), (7, 4), (6, 6), (9, 5), (8, 7)],
+        # cone rows (6,7) / (8,9): one local pivot (tail row -> b, coefficient s_psi) after a runtime
+        # role swap (head<->tail, b<->s_psi) when psi > s_psi; the other row/unknown goes to the tail
+        elim=[(2, 8), (4, 9), (3, 2), (5, 3), (7, 4), (9, 5)],
+        swaps=[((6, 7), (4, 6)), ((8, 9), (5, 7))],
         opts=dict(IP_DEFAULT, kappa_tol=1e-4, kappa_grad_tol=1e-4),       # examples/cartpole.jl:20
     )
 
@@ -333,14 +341,18 @@ def planar_push() -> ModelSpec:
     # static pivots: s1 row 5 -> z6; psi rows 6..10 -> z7..z11; vT rows 11..19 -> sb z26..z34;
     # bilinear row 20 -> gamma z5; cones: tail rows pivot on b (coef spsi), head on spsi.
     elim = [(5, 6)] + [(6 + i, 7 + i) for i in range(5)] + [(11 + i, 26 + i) for i in range(9)] + [(20, 5)]
+    swaps = []
     for i in range(4):
         base = 21 + 3 * i
-        elim += [(base + 1, 12 + 2 * i), (base + 2, 13 + 2 * i), (base, 21 + i)]
-    elim += [(34, 20), (33, 25)]
+        elim += [(base + 1, 12 + 2 * i)]
+        swaps += [((base, base + 1), (12 + 2 * i, 21 + i))]
+    elim += [(34, 20)]
+    swaps += [((33, 34), (20, 25))]
     return ModelSpec(
         name="planar_push", model_id=4, nq=nq, nu=nu, nz=nz, nth=nth, z=z, th=th, kappa=k, r=r,
         ort=([5], [6]), soc=soc, equr=list(range(20)), ortr=[20], socri=socri, bil=list(range(20, 35)),
-        z_init=z_init, kind="mech", nfric=0, idx_zq=list(range(5)), elim=elim,
+        z_init=z_init, kind="mech", nfric=0, idx_zq=list(range(5)), elim=elim, swaps=swaps,
+        floor_pivots=[(20, 5)],
         opts=dict(IP_DEFAULT, kappa_tol=1e-4, kappa_grad_tol=1e-2),       # examples/planar_push.jl:21-22
     )
 
@@ -390,7 +402,9 @@ def rocket_dynamics() -> ModelSpec:
     return ModelSpec(
         name="rocket_dynamics", model_id=5, nq=nx, nu=nu, nz=nz, nth=nth, z=z, th=th, kappa=k, r=r,
         ort=([], []), soc=[], equr=list(range(12)), ortr=[], socri=[], bil=[],   # simulator.jl:34-49
-        z_init=[("q", i) for i in range(12)], kind="rocket", idx_zq=list(range(12)), elim=[],
+        z_init=[("q", i) for i in range(12)], kind="rocket", idx_zq=list(range(12)),
+        # rz = I - (h/2) df/dx(mid) is diagonally dominant for the step sizes used -> static diagonal pivots
+        elim=[(i, i) for i in range(12)],
         # src/models/rocket/dynamics.jl:21-27 (other fields RoboDojo defaults [RECALL])
         opts=dict(r_tol=1e-8, kappa_tol=1.0, max_iter=100, max_ls=25, eps_min=0.25,
                   kappa_reg=1e-3, gamma_reg=0.1, undercut=5.0, kappa_grad_tol=1.0),
@@ -500,14 +514,15 @@ def hopper() -> ModelSpec:
             + [(8, 12), (9, 13)]                       # psi rows -> psi
             + [(10, 18), (11, 19)]                     # tangential velocity rows -> sb
             + [(12 + i, 4 + i) for i in range(4)]      # bilinear rows -> gamma (pivot s_gamma)
-            + [(17, 14), (16, 16), (19, 15), (18, 17)])  # cones: tail row -> b, head row -> s_psi
+            + [(17, 14), (19, 15)])                   # cones: tail row -> b (after the runtime role swap)
     return ModelSpec(
         name="hopper", model_id=7, nq=nq, nu=nu, nz=nz, nth=nth, z=z, th=th, kappa=k, r=r,
         ort=([4, 5, 6, 7], [8, 9, 10, 11]), soc=[([12, 14], [16, 18]), ([13, 15], [17, 19])],
         equr=list(range(12)), ortr=[12, 13, 14, 15], socri=[[16, 17], [18, 19]], bil=list(range(12, 20)),
         z_init=z_init, kind="mech", nfric=2,
         fric_default=[P["friction_body_world"], P["friction_foot_world"]],
-        idx_zq=[0, 1, 2, 3], elim=elim,
+        idx_zq=[0, 1, 2, 3], elim=elim, floor_pivots=[(12 + i, 4 + i) for i in range(4)],
+        swaps=[((16, 17), (14, 16)), ((18, 19), (15, 17))],
         opts=dict(IP_DEFAULT, kappa_tol=1e-4, kappa_grad_tol=1e-3),       # examples/hopper.jl:42
         notes="RoboDojo hopper, restated from recall; constants unverified",
     )

@@ -1,0 +1,503 @@
+// C ABI of libod_mi355x.so (include/od_mi355x.h): argument checking, view construction, launches.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/od_mi355x.h"
+#include "od_vtable.h"
+
+using namespace od;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define OD_HIP(call)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) return fail(OD_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+const ModelVT* vt_of(int model) {
+  switch (model) {
+    case OD_ACROBOT_IMPACT: return vt_acrobot_impact();
+    case OD_ACROBOT_NOMINAL: return vt_acrobot_nominal();
+    case OD_CARTPOLE_FRICTION: return vt_cartpole_friction();
+    case OD_CARTPOLE_FRICTIONLESS: return vt_cartpole_frictionless();
+    case OD_PLANAR_PUSH: return vt_planar_push();
+    case OD_ROCKET_DYNAMICS: return vt_rocket_dynamics();
+    case OD_ROCKET_PROJECTION: return vt_rocket_projection();
+    case OD_HOPPER: return vt_hopper();
+    default: return nullptr;
+  }
+}
+
+void defaults_of(const ModelVT* vt, od_options* o) {
+  o->r_tol = vt->r_tol;
+  o->kappa_eval_tol = vt->kappa_eval;
+  o->kappa_grad_tol = vt->kappa_grad;
+  o->max_iter = vt->max_iter;
+  o->max_ls = vt->max_ls;
+  o->eps_min = vt->eps_min;
+  o->kappa_reg = vt->kappa_reg;
+  o->gamma_reg = vt->gamma_reg;
+  o->undercut = vt->undercut >= 1e299 ? INFINITY : vt->undercut;
+}
+
+template <class T> Opts<T> to_opts(const od_options& o) {
+  Opts<T> r;
+  r.r_tol = (T)o.r_tol;
+  r.kappa_eval = (T)o.kappa_eval_tol;
+  r.kappa_grad = (T)o.kappa_grad_tol;
+  r.eps_min = (T)o.eps_min;
+  r.kappa_reg = (T)o.kappa_reg;
+  r.gamma_reg = (T)o.gamma_reg;
+  r.undercut_inv = std::isinf(o.undercut) ? T(0) : (T)(1.0 / o.undercut);
+  r.max_iter = o.max_iter;
+  r.max_ls = o.max_ls;
+  return r;
+}
+
+
+// Least-squares fit of src/ls.jl:44-60 for the cost of src/gradient_bundle.jl:35-39,
+//   sum_i | f_eta_i - f_z - M eta_i |^2 ,   M = ny x nzb,
+// in closed form (normal equations M * sum(eta eta') = sum((f_eta - f_z) eta')): the cost is exactly
+// quadratic, so the reference's Newton iteration lands on this minimiser in one step.
+// One lane per knot; sizes are runtime (tiny kernel, B = number of knots).
+constexpr int OD_LS_MAX = 24;
+__global__ __launch_bounds__(OD_BLOCK) void k_lsfit(long B, int N, int ny, int nzb, const double* eta,
+                                                   View<const double> feta, View<double> dz, View<int> status) {
+  const long b = (long)blockIdx.x * OD_BLOCK + threadIdx.x;
+  if (b >= B) return;
+  double A[OD_LS_MAX * OD_LS_MAX], R[OD_LS_MAX * OD_LS_MAX], fz[OD_LS_MAX], x[OD_LS_MAX];
+  int piv[OD_LS_MAX];
+  for (int i = 0; i < nzb * nzb; ++i) A[i] = 0.0;
+  for (int i = 0; i < ny * nzb; ++i) R[i] = 0.0;
+  const long p0 = b * (N + 1);
+  for (int a = 0; a < ny; ++a) fz[a] = feta.at(a, p0);
+  for (int i = 0; i < N; ++i) {
+    const double* e = eta + (long)nzb * i;
+    for (int c = 0; c < nzb; ++c)
+      for (int r = 0; r < nzb; ++r) A[r + nzb * c] += e[r] * e[c];
+    for (int c = 0; c < nzb; ++c)
+      for (int a = 0; a < ny; ++a) R[a + ny * c] += (feta.at(a, p0 + 1 + i) - fz[a]) * e[c];
+  }
+  bool ok = true;
+  for (int k = 0; k < nzb; ++k) {   // LU with partial pivoting (RoboDojo lu_solver, src/ls.jl:52)
+    int p = k;
+    double best = fabs(A[k + nzb * k]);
+    for (int i = k + 1; i < nzb; ++i) { const double v = fabs(A[i + nzb * k]); if (v > best) { best = v; p = i; } }
+    piv[k] = p;
+    ok = ok && (best > 0.0);
+    if (p != k) for (int j = 0; j < nzb; ++j) { const double t = A[k + nzb * j]; A[k + nzb * j] = A[p + nzb * j]; A[p + nzb * j] = t; }
+    const double inv = 1.0 / A[k + nzb * k];
+    for (int i = k + 1; i < nzb; ++i) A[i + nzb * k] *= inv;
+    for (int j = k + 1; j < nzb; ++j) { const double ukj = A[k + nzb * j]; for (int i = k + 1; i < nzb; ++i) A[i + nzb * j] -= A[i + nzb * k] * ukj; }
+  }
+  for (int a = 0; a < ny; ++a) {
+    for (int c = 0; c < nzb; ++c) x[c] = R[a + ny * c];
+    for (int k = 0; k < nzb; ++k) { const int p = piv[k]; if (p != k) { const double t = x[k]; x[k] = x[p]; x[p] = t; } }
+    for (int k = 0; k < nzb; ++k) for (int i = k + 1; i < nzb; ++i) x[i] -= A[i + nzb * k] * x[k];
+    for (int k = nzb - 1; k >= 0; --k) { x[k] /= A[k + nzb * k]; for (int i = 0; i < k; ++i) x[i] -= A[i + nzb * k] * x[k]; }
+    for (int c = 0; c < nzb; ++c) dz.at(a + ny * c, b) = x[c];
+  }
+  if (status.ok()) status.at(0, b) = ok ? 1 : 0;
+}
+
+}  // namespace
+
+struct od_handle_s {
+  const ModelVT* vt;
+  int dtype, layout;
+  od_options opts;
+  double h, fric[4], u_max;
+  hipStream_t stream;
+  double* stage;   // device staging for the host scalar path
+  size_t stage_elems;
+};
+
+namespace {
+
+template <class T> View<T> mkview(void* p, long E, long K, int layout) {
+  View<T> v;
+  v.p = (T*)p;
+  if (layout == OD_LAYOUT_BATCH_MINOR) { v.se = K; v.sb = 1; }
+  else { v.se = 1; v.sb = E; }
+  return v;
+}
+template <class T> View<const T> mkcview(const void* p, long E, long K, int layout) {
+  View<const T> v;
+  v.p = (const T*)p;
+  if (layout == OD_LAYOUT_BATCH_MINOR) { v.se = K; v.sb = 1; }
+  else { v.se = 1; v.sb = E; }
+  return v;
+}
+
+// with cones and a finite undercut the centering floor depends on kappa_tol, so the two
+// simulators' iterates differ: the eval and grad solves must then be run separately.
+bool fusable(const od_handle_s* h) {
+  return std::isinf(h->opts.undercut) || h->opts.kappa_eval_tol == h->opts.kappa_grad_tol ||
+         h->vt->kind == 1 /* rocket dynamics: no cones */ ||
+         (h->vt->id == OD_ACROBOT_NOMINAL || h->vt->id == OD_CARTPOLE_FRICTIONLESS);
+}
+
+StepArgs<double> step_args(od_handle_s* h, long B, long K, const void* x, const void* u, void* d, void* dx,
+                           void* du, void* dq3, int* status, int* iters, int want_grad) {
+  const ModelVT* vt = h->vt;
+  const int nq = vt->nq, n = 2 * nq, nu = vt->nu, L = h->layout;
+  StepArgs<double> a;
+  a.B = B;
+  a.h = h->h;
+  for (int i = 0; i < 4; ++i) a.fric[i] = h->fric[i];
+  a.opts = to_opts<double>(h->opts);
+  a.x = mkcview<double>(x, n, B, L);
+  a.u = mkcview<double>(u, nu, K, L);
+  a.d = mkview<double>(d, n, K, L);
+  a.dx = mkview<double>(dx, n * n, K, L);
+  a.du = mkview<double>(du, n * nu, K, L);
+  a.dq3 = mkview<double>(dq3, nq * (n + nu), K, L);
+  a.status = mkview<int>(status, 1, K, L);
+  a.iters = mkview<int>(iters, 2, K, L);
+  a.want_grad = want_grad;
+  a.d_skip_q2 = 0;
+  return a;
+}
+
+int check_mech(od_handle_s* h, const char* fn) {
+  if (!h) return fail(OD_ERR_INVALID, std::string(fn) + ": null handle");
+  if (h->vt->kind != 0) return fail(OD_ERR_UNSUPPORTED, std::string(fn) + ": model is not a mechanical (q1,q2,u) model");
+  if (h->dtype != OD_F64) return fail(OD_ERR_UNSUPPORTED, std::string(fn) + ": mechanical models are instantiated for OD_F64 only");
+  return OD_OK;
+}
+
+int run_step(od_handle_s* h, const char* fn, long B, const void* x, const void* u, void* d, void* dx, void* du,
+             void* dq3, int* status, int* iters, int want_grad) {
+  if (int rc = check_mech(h, fn)) return rc;
+  if (B <= 0) return OD_OK;
+  if (!x || (h->vt->nu > 0 && !u)) return fail(OD_ERR_INVALID, std::string(fn) + ": null input");
+  StepArgs<double> a = step_args(h, B, B, x, u, d, dx, du, dq3, status, iters, want_grad);
+  if (want_grad && !fusable(h)) {
+    // two passes, exactly like the reference's eval_sim / grad_sim pair
+    StepArgs<double> e = a;
+    e.want_grad = 0; e.dx.p = nullptr; e.du.p = nullptr; e.dq3.p = nullptr;
+    OD_HIP(h->vt->step(e, h->stream));
+    StepArgs<double> g = a;
+    g.d.p = nullptr; g.opts.kappa_eval = g.opts.kappa_grad;
+    g.status.p = nullptr; g.iters.p = nullptr;
+    OD_HIP(h->vt->step(g, h->stream));
+    return OD_OK;
+  }
+  OD_HIP(h->vt->step(a, h->stream));
+  return OD_OK;
+}
+
+}  // namespace
+
+template <class T> static int rocket_impl(od_handle h, long B, int project, const void* x, const void* u, void* y,
+                                          void* dx, void* du, void* uproj, int* status) {
+  const int L = h->layout;
+  RocketArgs<T> a;
+  a.B = B;
+  a.h = (T)h->h;
+  a.u_max = (T)h->u_max;
+  a.opts_dyn = to_opts<T>(h->opts);
+  od_options po;
+  defaults_of(vt_rocket_projection(), &po);
+  if (h->dtype == OD_F32) {   // tolerances reachable in fp32
+    po.r_tol = std::fmax(po.r_tol, (double)h->opts.r_tol);
+  }
+  a.opts_proj = to_opts<T>(po);
+  a.project = project;
+  a.want_grad = (dx || du) ? 1 : 0;
+  a.x = mkcview<T>(x, 12, B, L);
+  a.u = mkcview<T>(u, 3, B, L);
+  a.y = mkview<T>(y, 12, B, L);
+  a.dx = mkview<T>(dx, 144, B, L);
+  a.du = mkview<T>(du, 36, B, L);
+  a.uproj = mkview<T>(uproj, 3, B, L);
+  a.status = mkview<int>(status, 1, B, L);
+  hipError_t e;
+  if constexpr (sizeof(T) == 8) e = launch_rocket64(a, h->stream);
+  else e = launch_rocket32(a, h->stream);
+  if (e != hipSuccess) return fail(OD_ERR_HIP, std::string("od_rocket launch: ") + hipGetErrorString(e));
+  return OD_OK;
+}
+
+
+extern "C" {
+
+int od_version(void) { return 100; }
+const char* od_last_error(void) { return g_err.c_str(); }
+
+int od_model_dims(int model, int* nq, int* nu, int* nz, int* ntheta, int* nfric) {
+  const ModelVT* vt = vt_of(model);
+  if (!vt) return fail(OD_ERR_INVALID, "od_model_dims: unknown model");
+  if (nq) *nq = vt->nq;
+  if (nu) *nu = vt->nu;
+  if (nz) *nz = vt->nz;
+  if (ntheta) *ntheta = vt->nth;
+  if (nfric) *nfric = vt->nfric;
+  return OD_OK;
+}
+
+const char* od_model_name(int model) {
+  const ModelVT* vt = vt_of(model);
+  return vt ? vt->name : nullptr;
+}
+
+int od_default_options(int model, od_options* out) {
+  const ModelVT* vt = vt_of(model);
+  if (!vt || !out) return fail(OD_ERR_INVALID, "od_default_options: bad arguments");
+  defaults_of(vt, out);
+  return OD_OK;
+}
+
+int od_raw_grad_dims(int model, int* nzq, int* ngc) {
+  const ModelVT* vt = vt_of(model);
+  if (!vt) return fail(OD_ERR_INVALID, "od_raw_grad_dims: unknown model");
+  if (nzq) *nzq = vt->nzq;
+  if (ngc) *ngc = vt->ngc;
+  return OD_OK;
+}
+
+int od_create(int model, int dtype, const od_options* opts, double dt, od_handle* out) {
+  const ModelVT* vt = vt_of(model);
+  if (!vt || !out) return fail(OD_ERR_INVALID, "od_create: bad arguments");
+  if (dtype != OD_F64 && dtype != OD_F32) return fail(OD_ERR_INVALID, "od_create: bad dtype");
+  if (dtype == OD_F32 && !vt->raw32)
+    return fail(OD_ERR_UNSUPPORTED, "od_create: OD_F32 is instantiated for the rocket models only");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(OD_ERR_NO_DEVICE, "od_create: no HIP device visible (this library has no CPU path)");
+  od_handle_s* h = new od_handle_s();
+  h->vt = vt;
+  h->dtype = dtype;
+  h->layout = OD_LAYOUT_BATCH_MINOR;
+  if (opts) h->opts = *opts; else defaults_of(vt, &h->opts);
+  h->h = dt;
+  for (int i = 0; i < 4; ++i) h->fric[i] = vt->fric_default[i];
+  h->u_max = 12.5;   // examples/rocket.jl:16
+  h->stream = nullptr;
+  h->stage = nullptr;
+  h->stage_elems = 0;
+  *out = h;
+  return OD_OK;
+}
+
+int od_destroy(od_handle h) {
+  if (!h) return OD_OK;
+  if (h->stage) (void)hipFree(h->stage);
+  delete h;
+  return OD_OK;
+}
+
+int od_set_options(od_handle h, const od_options* o) {
+  if (!h || !o) return fail(OD_ERR_INVALID, "od_set_options: bad arguments");
+  h->opts = *o;
+  return OD_OK;
+}
+int od_get_options(od_handle h, od_options* o) {
+  if (!h || !o) return fail(OD_ERR_INVALID, "od_get_options: bad arguments");
+  *o = h->opts;
+  return OD_OK;
+}
+int od_set_timestep(od_handle h, double dt) {
+  if (!h || !(dt > 0)) return fail(OD_ERR_INVALID, "od_set_timestep: bad arguments");
+  h->h = dt;
+  return OD_OK;
+}
+int od_set_friction(od_handle h, const double* mu, int n) {
+  if (!h || n != h->vt->nfric || (n > 0 && !mu)) return fail(OD_ERR_INVALID, "od_set_friction: model has a different number of friction coefficients");
+  for (int i = 0; i < n; ++i) h->fric[i] = mu[i];
+  return OD_OK;
+}
+int od_set_u_max(od_handle h, double u_max) {
+  if (!h) return fail(OD_ERR_INVALID, "od_set_u_max: null handle");
+  h->u_max = u_max;
+  return OD_OK;
+}
+int od_set_layout(od_handle h, int layout) {
+  if (!h || (layout != OD_LAYOUT_BATCH_MINOR && layout != OD_LAYOUT_BATCH_MAJOR)) return fail(OD_ERR_INVALID, "od_set_layout: bad arguments");
+  h->layout = layout;
+  return OD_OK;
+}
+int od_set_stream(od_handle h, void* s) {
+  if (!h) return fail(OD_ERR_INVALID, "od_set_stream: null handle");
+  h->stream = (hipStream_t)s;
+  return OD_OK;
+}
+int od_synchronize(od_handle h) {
+  if (!h) return fail(OD_ERR_INVALID, "od_synchronize: null handle");
+  OD_HIP(hipStreamSynchronize(h->stream));
+  return OD_OK;
+}
+
+int od_step(od_handle h, long B, const void* x, const void* u, void* d, int* status, int* iters) {
+  return run_step(h, "od_step", B, x, u, d, nullptr, nullptr, nullptr, status, iters, 0);
+}
+
+int od_step_grad(od_handle h, long B, const void* x, const void* u, void* d, void* dx, void* du, int* status, int* iters) {
+  return run_step(h, "od_step_grad", B, x, u, d, dx, du, nullptr, status, iters, 1);
+}
+
+int od_step_grad_compact(od_handle h, long B, const void* x, const void* u, void* q3, void* dq3, int* status, int* iters) {
+  if (int rc = check_mech(h, "od_step_grad_compact")) return rc;
+  if (B <= 0) return OD_OK;
+  // q3 is the second half of d: give the d view an offset so that rows nq.. land in q3
+  const int nq = h->vt->nq;
+  StepArgs<double> a = step_args(h, B, B, x, u, nullptr, nullptr, nullptr, dq3, status, iters, dq3 ? 1 : 0);
+  if (q3) {
+    View<double> v = mkview<double>(q3, nq, B, h->layout);
+    v.p -= (long)nq * v.se;   // element nq+i of the virtual d vector -> element i of q3
+    a.d = v;
+    a.d_skip_q2 = 1;
+  }
+  if (a.want_grad && !fusable(h)) return fail(OD_ERR_UNSUPPORTED, "od_step_grad_compact: finite undercut with kappa_eval != kappa_grad; use od_step + od_step_grad");
+  OD_HIP(h->vt->step(a, h->stream));
+  return OD_OK;
+}
+
+int od_rollout(od_handle h, long B, int T, const void* x1, const void* U, void* X, void* A, void* Bm, int* status, int* iters) {
+  if (int rc = check_mech(h, "od_rollout")) return rc;
+  if (B <= 0 || T <= 0) return OD_OK;
+  if (!x1 || !U || !X) return fail(OD_ERR_INVALID, "od_rollout: null x1/U/X");
+  if (!fusable(h) && (A || Bm)) return fail(OD_ERR_UNSUPPORTED, "od_rollout: finite undercut with kappa_eval != kappa_grad");
+  const int n = 2 * h->vt->nq;
+  const long K = (long)T * B;
+  RolloutArgs<double> r;
+  r.s = step_args(h, B, K, x1, U, nullptr, A, Bm, nullptr, status, iters, (A || Bm) ? 1 : 0);
+  // X has (T+1)*B slots; knot k's d goes to slot k + B
+  View<double> xv = mkview<double>(X, n, (long)(T + 1) * B, h->layout);
+  r.x0 = xv;
+  xv.p += (long)B * xv.sb;
+  r.s.d = xv;
+  r.Tn = T;
+  OD_HIP(h->vt->rollout(r, h->stream));
+  return OD_OK;
+}
+
+size_t od_bundle_workspace_bytes(od_handle h, long B, int N) {
+  if (!h || B <= 0 || N <= 0) return 0;
+  return sizeof(double) * (size_t)h->vt->nq * (size_t)(N + 1) * (size_t)B + sizeof(int) * (size_t)(N + 1) * (size_t)B;
+}
+
+int od_bundle_grad(od_handle h, long B, int N, const void* x, const void* u, const void* eta, void* dz,
+                   void* ws, size_t ws_bytes, int* status) {
+  if (int rc = check_mech(h, "od_bundle_grad")) return rc;
+  if (B <= 0) return OD_OK;
+  if (N <= 0 || !x || !eta || !dz || !ws) return fail(OD_ERR_INVALID, "od_bundle_grad: bad arguments");
+  if (ws_bytes < od_bundle_workspace_bytes(h, B, N)) return fail(OD_ERR_INVALID, "od_bundle_grad: workspace too small");
+  const int nq = h->vt->nq, nzb = 2 * nq + h->vt->nu;
+  const long P = (long)(N + 1) * B;
+  BundleArgs<double> a;
+  a.s = step_args(h, B, B, x, u, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+  a.N = N;
+  a.eta = (const double*)eta;
+  a.feta = mkview<double>(ws, nq, P, OD_LAYOUT_BATCH_MINOR);
+  a.status = mkview<int>((char*)ws + sizeof(double) * (size_t)nq * P, 1, P, OD_LAYOUT_BATCH_MINOR);
+  OD_HIP(h->vt->bundle(a, P, h->stream));
+  View<const double> fv;
+  fv.p = a.feta.p; fv.se = a.feta.se; fv.sb = a.feta.sb;
+  hipLaunchKernelGGL(k_lsfit, od_grid(B), dim3(OD_BLOCK), 0, h->stream, B, N, nq, nzb, (const double*)eta, fv,
+                     mkview<double>(dz, nq * nzb, B, h->layout), mkview<int>(status, 1, B, h->layout));
+  OD_HIP(hipGetLastError());
+  return OD_OK;
+}
+
+int od_ls_fit(od_handle h, long B, int N, int ny, int nzb, const void* eta, const void* feta, void* M, int* status) {
+  if (!h) return fail(OD_ERR_INVALID, "od_ls_fit: null handle");
+  if (B <= 0) return OD_OK;
+  if (N <= 0 || ny <= 0 || nzb <= 0 || ny > OD_LS_MAX || nzb > OD_LS_MAX || !eta || !feta || !M)
+    return fail(OD_ERR_INVALID, "od_ls_fit: bad arguments (ny, nzb <= 24)");
+  View<const double> fv = mkcview<double>(feta, ny, (long)(N + 1) * B, OD_LAYOUT_BATCH_MINOR);
+  hipLaunchKernelGGL(k_lsfit, od_grid(B), dim3(OD_BLOCK), 0, h->stream, B, N, ny, nzb, (const double*)eta, fv,
+                     mkview<double>(M, ny * nzb, B, h->layout), mkview<int>(status, 1, B, h->layout));
+  OD_HIP(hipGetLastError());
+  return OD_OK;
+}
+
+int od_ip_solve(od_handle h, long B, const void* z0, const void* theta, void* z, void* dz, int* status, int* iters) {
+  if (!h) return fail(OD_ERR_INVALID, "od_ip_solve: null handle");
+  if (B <= 0) return OD_OK;
+  if (!z0 || !theta || !z) return fail(OD_ERR_INVALID, "od_ip_solve: null z0/theta/z");
+  const ModelVT* vt = h->vt;
+  const int L = h->layout;
+  if (h->dtype == OD_F64) {
+    RawArgs<double> a;
+    a.B = B;
+    a.opts = to_opts<double>(h->opts);
+    if (!dz) a.opts.kappa_grad = a.opts.kappa_eval;
+    a.z0 = mkcview<double>(z0, vt->nz, B, L);
+    a.th = mkcview<double>(theta, vt->nth, B, L);
+    a.z = mkview<double>(z, vt->nz, B, L);
+    a.dz = mkview<double>(dz, vt->nzq * vt->ngc, B, L);
+    a.status = mkview<int>(status, 1, B, L);
+    a.iters = mkview<int>(iters, 2, B, L);
+    a.want_grad = dz ? 1 : 0;
+    OD_HIP(vt->raw64(a, h->stream));
+  } else {
+    RawArgs<float> a;
+    a.B = B;
+    a.opts = to_opts<float>(h->opts);
+    if (!dz) a.opts.kappa_grad = a.opts.kappa_eval;
+    a.z0 = mkcview<float>(z0, vt->nz, B, L);
+    a.th = mkcview<float>(theta, vt->nth, B, L);
+    a.z = mkview<float>(z, vt->nz, B, L);
+    a.dz = mkview<float>(dz, vt->nzq * vt->ngc, B, L);
+    a.status = mkview<int>(status, 1, B, L);
+    a.iters = mkview<int>(iters, 2, B, L);
+    a.want_grad = dz ? 1 : 0;
+    OD_HIP(vt->raw32(a, h->stream));
+  }
+  return OD_OK;
+}
+
+int od_rocket(od_handle h, long B, int project, const void* x, const void* u, void* y, void* dx, void* du,
+              void* uproj, int* status) {
+  if (!h) return fail(OD_ERR_INVALID, "od_rocket: null handle");
+  if (h->vt->id != OD_ROCKET_DYNAMICS) return fail(OD_ERR_UNSUPPORTED, "od_rocket: needs an OD_ROCKET_DYNAMICS handle");
+  if (B <= 0) return OD_OK;
+  if (!x || !u) return fail(OD_ERR_INVALID, "od_rocket: null input");
+  if (h->dtype == OD_F64) return rocket_impl<double>(h, B, project, x, u, y, dx, du, uproj, status);
+  return rocket_impl<float>(h, B, project, x, u, y, dx, du, uproj, status);
+}
+
+// ---- host scalar path ------------------------------------------------------------------------
+static int host_call(od_handle h, const double* x, const double* u, double* d, double* dx, double* du) {
+  if (int rc = check_mech(h, "od_f_host")) return rc;
+  const int n = 2 * h->vt->nq, nu = h->vt->nu;
+  const size_t need = (size_t)n + nu + n + (size_t)n * n + (size_t)n * nu;
+  if (h->stage_elems < need) {
+    if (h->stage) (void)hipFree(h->stage);
+    OD_HIP(hipMalloc((void**)&h->stage, need * sizeof(double)));
+    h->stage_elems = need;
+  }
+  double* dxp = h->stage;
+  double* dup = dxp + n;
+  double* ddp = dup + nu;
+  double* dAp = ddp + n;
+  double* dBp = dAp + (size_t)n * n;
+  OD_HIP(hipMemcpyAsync(dxp, x, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (nu) OD_HIP(hipMemcpyAsync(dup, u, nu * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const int want_grad = (dx || du) ? 1 : 0;
+  int rc = run_step(h, "od_f_host", 1, dxp, dup, d ? ddp : nullptr, dx ? dAp : nullptr, du ? dBp : nullptr, nullptr,
+                    nullptr, nullptr, want_grad);
+  if (rc) return rc;
+  if (d) OD_HIP(hipMemcpyAsync(d, ddp, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (dx) OD_HIP(hipMemcpyAsync(dx, dAp, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (du) OD_HIP(hipMemcpyAsync(du, dBp, (size_t)n * nu * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  OD_HIP(hipStreamSynchronize(h->stream));
+  return OD_OK;
+}
+
+int od_f_host(od_handle h, const double* x, const double* u, double* d) { return host_call(h, x, u, d, nullptr, nullptr); }
+int od_fx_host(od_handle h, const double* x, const double* u, double* dx) { return host_call(h, x, u, nullptr, dx, nullptr); }
+int od_fu_host(od_handle h, const double* x, const double* u, double* du) { return host_call(h, x, u, nullptr, nullptr, du); }
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// Scalar helpers shared by the generated model code and the interior-point solver.
+// Device code for gfx950 (hipcc); the same header also compiles with a host C++ compiler so that
+// tests/ can exercise the solver logic on CPU against the oracle (test harness only -- the shipped
+// library has no CPU path).
+#pragma once
+#include <cmath>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define OD_HD __host__ __device__ __forceinline__
+#else
+#define OD_HD inline
+#endif
+
+// floor for static pivots on orthant slack variables (strictly positive, may underflow at convergence)
+#define OD_PIVOT_FLOOR 1e-12
+
+namespace od {
+
+OD_HD double od_sin(double x) { return sin(x); }
+OD_HD double od_cos(double x) { return cos(x); }
+OD_HD double od_sqrt(double x) { return sqrt(x); }
+OD_HD double od_abs(double x) { return fabs(x); }
+OD_HD double od_pow(double x, double y) { return pow(x, y); }
+OD_HD float od_sin(float x) { return sinf(x); }
+OD_HD float od_cos(float x) { return cosf(x); }
+OD_HD float od_sqrt(float x) { return sqrtf(x); }
+OD_HD float od_abs(float x) { return fabsf(x); }
+OD_HD float od_pow(float x, float y) { return powf(x, y); }
+
+template <class T> OD_HD T od_min(T a, T b) { return a < b ? a : b; }
+template <class T> OD_HD T od_max(T a, T b) { return a > b ? a : b; }
+
+// x^N by repeated squaring (N known at code-generation time)
+template <int N, class T> OD_HD T od_powi(T x) {
+  if constexpr (N == 0) return T(1);
+  else if constexpr (N == 1) return x;
+  else if constexpr (N % 2 == 0) { const T h = od_powi<N / 2>(x); return h * h; }
+  else return x * od_powi<N - 1>(x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense LU with partial pivoting for the small "tail" block left after the static elimination
+// (N = nq for the mechanical models).  Fully unrolled; row exchanges are done with selects so the
+// N*N block stays in registers (no dynamically indexed private array -> no scratch).
+// A is column-major N x N, overwritten by L\U of P*A.
+// ---------------------------------------------------------------------------------------------
+template <class T, int N> OD_HD bool od_lu_factor(T* A, int* piv) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    int p = k;
+    T best = od_abs(A[k + N * k]);
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) {
+      const T v = od_abs(A[i + N * k]);
+      if (v > best) { best = v; p = i; }
+    }
+    piv[k] = p;
+    ok = ok && (best > T(0));
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) {
+      const bool sw = (p == i);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const T u = A[k + N * j], w = A[i + N * j];
+        A[k + N * j] = sw ? w : u;
+        A[i + N * j] = sw ? u : w;
+      }
+    }
+    const T inv = T(1) / A[k + N * k];
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) A[i + N * k] *= inv;
+#pragma unroll
+    for (int j = k + 1; j < N; ++j) {
+      const T ukj = A[k + N * j];
+#pragma unroll
+      for (int i = k + 1; i < N; ++i) A[i + N * j] -= A[i + N * k] * ukj;
+    }
+  }
+  return ok;
+}
+
+template <class T, int N> OD_HD void od_lu_solve(const T* A, const int* piv, T* b) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const int p = piv[k];
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) {
+      const bool sw = (p == i);
+      const T u = b[k], w = b[i];
+      b[k] = sw ? w : u;
+      b[i] = sw ? u : w;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) b[i] -= A[i + N * k] * b[k];
+  }
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {
+    b[k] /= A[k + N * k];
+#pragma unroll
+    for (int i = 0; i < k; ++i) b[i] -= A[i + N * k] * b[k];
+  }
+}
+
+}  // namespace od

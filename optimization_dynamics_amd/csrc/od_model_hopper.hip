@@ -1,0 +1,4 @@
+#define OD_MODEL hopper
+#define OD_MODEL_MECH 1
+#define OD_MODEL_FP32 0
+#include "od_model_tu.inc"

@@ -1,0 +1,24 @@
+// Fused rocket kernels: thrust-cone SOCP projection -> implicit-midpoint dynamics solve ->
+// implicit gradients and the 12x3 * 3x3 chain product, one lane per knot
+// (src/models/rocket/dynamics.jl:101-268).
+#include "od_vtable.h"
+#include "gen/rocket_dynamics.h"
+#include "gen/rocket_projection.h"
+
+namespace od {
+
+template <class T> __global__ __launch_bounds__(OD_BLOCK) void k_rocket(RocketArgs<T> a) {
+  const long b = (long)blockIdx.x * OD_BLOCK + threadIdx.x;
+  if (b < a.B) unit_rocket<Model_rocket_dynamics, Model_rocket_projection, T>(a, b);
+}
+
+hipError_t launch_rocket64(const RocketArgs<double>& a, hipStream_t s) {
+  hipLaunchKernelGGL((k_rocket<double>), od_grid(a.B), dim3(OD_BLOCK), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_rocket32(const RocketArgs<float>& a, hipStream_t s) {
+  hipLaunchKernelGGL((k_rocket<float>), od_grid(a.B), dim3(OD_BLOCK), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace od

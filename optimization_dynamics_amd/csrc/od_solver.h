@@ -1,0 +1,259 @@
+// Per-problem interior-point step + implicit gradient, one problem per GPU lane.
+//
+// Replaces the reference's per-timestep inner solve
+//   RoboDojo.step!(sim, q2, v1, u, 1)                       (src/dynamics.jl:88,103,123)
+//   interior_point_solve!(ip)                               (src/models/rocket/dynamics.jl:109..262)
+// for all three of the reference's per-knot calls (f at kappa_eval; fx and fu at kappa_grad) in ONE
+// pass: with undercut = Inf (src/dynamics.jl:26) the centering target sigma*mu does not depend on
+// kappa_tol, so the kappa_grad solve's iterates are a prefix of the kappa_eval solve's.  The loop
+// snapshots the implicit gradient dz = -rz^{-1} rtheta at the first iterate satisfying
+// (r_tol, kappa_grad) and the state at the first iterate satisfying (r_tol, kappa_eval).
+//
+// All model structure (index sets, sparse KKT elimination) is compile-time (csrc/gen/*.h), every
+// loop below is fully unrolled and every array lives in registers.
+#pragma once
+#include "od_math.h"
+
+namespace od {
+
+template <class T> struct Opts {
+  T r_tol, kappa_eval, kappa_grad, eps_min, kappa_reg, gamma_reg, undercut_inv;
+  int max_iter, max_ls;
+};
+
+enum : int { OD_ST_EVAL_OK = 1, OD_ST_GRAD_OK = 2, OD_ST_FACTOR_OK = 4 };
+
+template <class M, class T> OD_HD T viol_eq(const T* r) {
+  T v = T(0);
+#pragma unroll
+  for (int i = 0; i < M::NEQ; ++i) { const T a = od_abs(r[M::EQUR[i]]); v = (a > v || a != a) ? a : v; }
+  return v;
+}
+template <class M, class T> OD_HD T viol_bil(const T* r) {
+  T v = T(0);
+  if constexpr (M::NBIL > 0) {
+#pragma unroll
+    for (int i = 0; i < M::NBIL; ++i) { const T a = od_abs(r[M::BIL[i]]); v = (a > v || a != a) ? a : v; }
+  }
+  return v;
+}
+
+// CVXOPT sec. 8.2 step to the boundary of a second-order cone for lam + alpha*dlt
+template <int N, class T> OD_HD T soc_step_one(const T* lam, const T* dlt, T tau) {
+  const T eps = T(1e-14);
+  const T l0 = lam[0];
+  T ll = l0 * l0, ld = l0 * dlt[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i) { ll -= lam[i] * lam[i]; ld -= lam[i] * dlt[i]; }
+  ll = od_max(ll, T(1e-25)) + eps;
+  ld += eps;
+  const T sq = od_sqrt(ll);
+  const T rs = ld / ll;
+  const T c = (ld / sq + dlt[0]) / (l0 / sq + T(1));
+  T nv = T(0);
+#pragma unroll
+  for (int i = 1; i < N; ++i) { const T rv = dlt[i] / sq - c * lam[i] / ll; nv += rv * rv; }
+  nv = od_sqrt(nv);
+  T a = T(1);
+  if (nv - rs > T(0)) a = od_min(a, tau / (nv - rs));
+  return a;
+}
+
+template <class M, int C, class T> OD_HD T soc_step_cone(const T* z, const T* D, T tau, T a) {
+  constexpr int o = M::SOCOFF[C], n = M::SOCOFF[C + 1] - M::SOCOFF[C];
+  T lam[n], dl[n];
+#pragma unroll
+  for (int i = 0; i < n; ++i) { lam[i] = z[M::SOC1[o + i]]; dl[i] = -D[M::SOC1[o + i]]; }
+  a = od_min(a, soc_step_one<n>(lam, dl, tau));
+#pragma unroll
+  for (int i = 0; i < n; ++i) { lam[i] = z[M::SOC2[o + i]]; dl[i] = -D[M::SOC2[o + i]]; }
+  a = od_min(a, soc_step_one<n>(lam, dl, tau));
+  if constexpr (C + 1 < M::NSOC) return soc_step_cone<M, C + 1>(z, D, tau, a);
+  else return a;
+}
+
+// largest alpha in (0,1] keeping z - alpha*D inside the cones (fractions tau_ort / tau_soc)
+template <class M, class T> OD_HD T step_length(const T* z, const T* D, T tau_ort, T tau_soc) {
+  T a = T(1);
+  if constexpr (M::NORT > 0) {
+#pragma unroll
+    for (int i = 0; i < M::NORT; ++i) {
+      const int k1 = M::ORT1[i], k2 = M::ORT2[i];
+      if (D[k1] > T(0)) a = od_min(a, tau_ort * z[k1] / D[k1]);
+      if (D[k2] > T(0)) a = od_min(a, tau_ort * z[k2] / D[k2]);
+    }
+  }
+  if constexpr (M::NSOC > 0) a = soc_step_cone<M, 0>(z, D, tau_soc, a);
+  return a;
+}
+
+// CVXOPT sec. 5.1.3 centering: mu = <primal,dual>/ncones ; sigma = clamp(mu_aff/mu, 0, 1)^3
+template <class M, class T> OD_HD T centering_kappa(const T* z, const T* Da, T aaff) {
+  constexpr int n = M::NORT + M::NSOC;
+  T s = T(0), sa = T(0);
+  if constexpr (M::NORT > 0) {
+#pragma unroll
+    for (int i = 0; i < M::NORT; ++i) {
+      const int a = M::ORT1[i], b = M::ORT2[i];
+      s += z[a] * z[b];
+      sa += (z[a] - aaff * Da[a]) * (z[b] - aaff * Da[b]);
+    }
+  }
+  if constexpr (M::NSOC > 0) {
+#pragma unroll
+    for (int k = 0; k < M::SOCOFF[M::NSOC]; ++k) {
+      const int a = M::SOC1[k], b = M::SOC2[k];
+      s += z[a] * z[b];
+      sa += (z[a] - aaff * Da[a]) * (z[b] - aaff * Da[b]);
+    }
+  }
+  const T mu = s / T(n);
+  T q = (sa / T(n)) / mu;
+  q = od_max(q, T(0));
+  q = od_min(q, T(1));
+  return q * q * q * mu;
+}
+
+template <class M, int C, class T> OD_HD void correction_cone(T* r, const T* Da) {
+  constexpr int o = M::SOCOFF[C], n = M::SOCOFF[C + 1] - M::SOCOFF[C];
+  T dot = T(0);
+#pragma unroll
+  for (int i = 0; i < n; ++i) dot += Da[M::SOC1[o + i]] * Da[M::SOC2[o + i]];
+  r[M::SOCR[o]] += dot;
+#pragma unroll
+  for (int i = 1; i < n; ++i)
+    r[M::SOCR[o + i]] += Da[M::SOC1[o]] * Da[M::SOC2[o + i]] + Da[M::SOC2[o]] * Da[M::SOC1[o + i]];
+  if constexpr (C + 1 < M::NSOC) correction_cone<M, C + 1>(r, Da);
+}
+
+// rz evaluated with the orthant variables clamped from below at reg (regularisation of
+// rz!(ip, rz, z, theta; reg)), then factored.
+template <class M, class T> OD_HD bool eval_factor(const T* z, const T* th, T reg, typename M::template Fact<T>& f) {
+  T zr[M::NZ];
+#pragma unroll
+  for (int i = 0; i < M::NZ; ++i) zr[i] = z[i];
+  if constexpr (M::NORT > 0) {
+#pragma unroll
+    for (int i = 0; i < M::NORT; ++i) {
+      zr[M::ORT1[i]] = od_max(zr[M::ORT1[i]], reg);
+      zr[M::ORT2[i]] = od_max(zr[M::ORT2[i]], reg);
+    }
+  }
+  T a[M::NNZ];
+  M::eval_rz(zr, th, a);
+  return M::factor(a, f);
+}
+
+// Sink concept:  void grad(int i /*row in ZQ*/, int c /*grad column*/, T v)
+//
+// z: in = initial guess, out = iterate at (r_tol, kappa_eval) convergence (or the last iterate).
+// Returns status bits; iters[0] = iterations to kappa_eval, iters[1] = iterations to kappa_grad.
+template <class M, class T, class Sink>
+OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, bool want_grad, Sink& sink, int* iters) {
+  constexpr bool CONES = (M::NORT + M::NSOC) > 0;
+  T r[M::NZ], zs[M::NZ];
+  M::eval_r(z, th, r);
+  T r_vio = viol_eq<M>(r), k_vio = viol_bil<M>(r);
+  bool eval_done = !want_state, grad_done = !want_grad;
+  int status = OD_ST_FACTOR_OK;
+  T reg_prev = T(0);
+  iters[0] = iters[1] = 0;
+  typename M::template Fact<T> f;
+  int it = 0;
+  for (;; ++it) {
+    const bool req = r_vio < o.r_tol;
+    const bool last = it >= o.max_iter;
+    if (!grad_done && ((req && k_vio < o.kappa_grad) || last)) {
+      // differentiate_solution!: dz = -rz(z*)^{-1} rtheta(z*), reg = max(reg_val, kappa_tol*gamma_reg)
+      const T reg = od_max(reg_prev, o.kappa_grad * o.gamma_reg);
+      if (!eval_factor<M>(z, th, reg, f)) status &= ~OD_ST_FACTOR_OK;
+      T g[M::NNZTH];
+      M::eval_rth(z, th, g);
+      for (int c = 0; c < M::NGC; ++c) {
+        T b[M::NZ];
+#pragma unroll
+        for (int i = 0; i < M::NZ; ++i) b[i] = T(0);
+#pragma unroll
+        for (int k = 0; k < M::NNZTH; ++k) b[M::RTH_ROW[k]] = (M::RTH_COL[k] == c) ? g[k] : b[M::RTH_ROW[k]];
+        M::solve(f, b, b);
+#pragma unroll
+        for (int i = 0; i < M::NZQ; ++i) sink.grad(i, c, -b[M::ZQ[i]]);
+      }
+      grad_done = true;
+      iters[1] = it;
+      if (!last) status |= OD_ST_GRAD_OK;
+    }
+    if (!eval_done && ((req && k_vio < o.kappa_eval) || last)) {
+#pragma unroll
+      for (int i = 0; i < M::NZ; ++i) zs[i] = z[i];
+      eval_done = true;
+      iters[0] = it;
+      if (!last) status |= OD_ST_EVAL_OK;
+    }
+    if (eval_done && grad_done) break;
+
+    const T reg = (k_vio < o.kappa_reg) ? k_vio * o.gamma_reg : T(0);
+    reg_prev = reg;
+    if (!eval_factor<M>(z, th, reg, f)) status &= ~OD_ST_FACTOR_OK;
+    T D[M::NZ];
+    M::solve(f, r, D);                                   // affine (predictor) direction
+    if constexpr (CONES) {
+      const T aaff = step_length<M>(z, D, T(1), T(1));
+      T kap = centering_kappa<M>(z, D, aaff);
+      kap = od_max(kap, o.kappa_eval * o.undercut_inv);
+#pragma unroll
+      for (int i = 0; i < M::NKROWS; ++i) r[M::KROWS[i]] -= kap;    // r(z; kappa) from r(z; 0)
+      if constexpr (M::NORT > 0) {
+#pragma unroll
+        for (int i = 0; i < M::NORT; ++i) r[M::ORTR[i]] += D[M::ORT1[i]] * D[M::ORT2[i]];
+      }
+      if constexpr (M::NSOC > 0) correction_cone<M, 0>(r, D);
+      M::solve(f, r, D);                                 // corrector direction, factors reused
+    }
+    const T vio = od_max(r_vio, k_vio);
+    const T tau = T(1) - od_min(o.eps_min, vio * vio);
+    T alpha = step_length<M>(z, D, tau, od_min(tau, T(0.99)));
+    T zc[M::NZ];
+    T r_c = T(0), k_c = T(0);
+    for (int ls = 0; ls < o.max_ls; ++ls) {
+#pragma unroll
+      for (int i = 0; i < M::NZ; ++i) zc[i] = z[i] - alpha * D[i];
+      M::eval_r(zc, th, r);
+      r_c = viol_eq<M>(r);
+      k_c = viol_bil<M>(r);
+      if (r_c <= r_vio || k_c <= k_vio) break;
+      alpha *= T(0.5);
+    }
+#pragma unroll
+    for (int i = 0; i < M::NZ; ++i) z[i] = zc[i];
+    r_vio = r_c;
+    k_vio = k_c;
+  }
+  if (want_state) {
+#pragma unroll
+    for (int i = 0; i < M::NZ; ++i) z[i] = zs[i];
+  }
+  return status;
+}
+
+// theta = [q2 - h*v1 ; q2 ; u ; friction ; h] and z0 = initialize_z!(q2) for the mechanical models
+// (RoboDojo.step! as called from src/dynamics.jl:82-88); v1 = (q2 - q1)/h.
+template <class M, class T> OD_HD void mech_setup(const T* q1, const T* q2, const T* u, const T* fric, T h, T* th, T* z) {
+#pragma unroll
+  for (int i = 0; i < M::NQ; ++i) {
+    const T v1 = (q2[i] - q1[i]) / h;
+    th[i] = q2[i] - h * v1;
+    th[M::NQ + i] = q2[i];
+  }
+#pragma unroll
+  for (int i = 0; i < M::NU; ++i) th[2 * M::NQ + i] = u[i];
+  if constexpr (M::NFRIC > 0) {
+#pragma unroll
+    for (int i = 0; i < M::NFRIC; ++i) th[2 * M::NQ + M::NU + i] = fric[i];
+  }
+  th[2 * M::NQ + M::NU + M::NFRIC] = h;
+#pragma unroll
+  for (int i = 0; i < M::NZ; ++i) z[i] = M::ZI_KIND[i] == 0 ? q2[M::ZI_IDX[i]] : T(M::ZI_VAL[i]);
+}
+
+}  // namespace od

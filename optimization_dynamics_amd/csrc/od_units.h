@@ -1,0 +1,279 @@
+// Per-problem "units of work" = what one GPU lane does.  Each unit mirrors one reference entry
+// point; the HIP kernels in od_kernels.hip just map lanes to units.  (tests/ also compiles this
+// header on the host to check the logic against the oracle; that harness is not shipped.)
+#pragma once
+#include "od_solver.h"
+
+namespace od {
+
+// strided view: element e of problem b lives at p[e*se + b*sb]
+//   batch-minor SoA (coalesced across lanes): se = batch capacity, sb = 1
+//   batch-major  (Julia n x B matrix)       : se = 1, sb = elements per problem
+template <class T> struct View {
+  T* p;
+  long se, sb;
+  OD_HD T& at(long e, long b) const { return p[e * se + b * sb]; }
+  OD_HD bool ok() const { return p != nullptr; }
+};
+
+// ---- f / fx / fu fused (src/dynamics.jl:81-128) ----------------------------------------------
+template <class T> struct StepArgs {
+  long B;
+  T h;
+  T fric[4];
+  Opts<T> opts;
+  View<const T> x;   // 2nq per problem: [q1; q2]
+  View<const T> u;   // nu
+  View<T> d;         // 2nq: [q2; q3]                                  (f)
+  View<T> dx;        // 2nq x 2nq col-major, ALL entries written        (fx)
+  View<T> du;        // 2nq x nu  col-major, ALL entries written        (fu)
+  View<T> dq3;       // compact nq x (2nq+nu) col-major = d q3/d(q1,q2,u) (alternative to dx/du)
+  View<int> status;  // bit0 eval converged, bit1 grad converged, bit2 factorisation ok
+  View<int> iters;   // 2 per problem: iterations to kappa_eval / kappa_grad
+  int want_grad;
+  int d_skip_q2;     // 1: only rows nq..2nq of d are written (compact q3 output)
+};
+
+template <class M, class T> struct StepSink {
+  const StepArgs<T>& a;
+  long b;
+  OD_HD void grad(int i, int c, T v) {
+    constexpr int nq = M::NQ, n = 2 * M::NQ;
+    if (a.dq3.ok()) a.dq3.at(i + nq * c, b) = v;
+    if (c < n) { if (a.dx.ok()) a.dx.at((nq + i) + n * c, b) = v; }
+    else { if (a.du.ok()) a.du.at((nq + i) + n * (c - n), b) = v; }
+  }
+};
+
+// one knot: x=[q1;q2], u -> d=[q2;q3], dx, du.  Returns status.
+template <class M, class T>
+OD_HD int unit_step_core(const StepArgs<T>& a, long b, const T* xin, const T* uin, T* q3out) {
+  constexpr int nq = M::NQ, n = 2 * M::NQ;
+  T th[M::NTH], z[M::NZ];
+  mech_setup<M>(xin, xin + nq, uin, a.fric, a.h, th, z);
+  StepSink<M, T> sink{a, b};
+  int it[2];
+  const int st = ip_step_grad<M>(a.opts, th, z, true, a.want_grad != 0, sink, it);
+#pragma unroll
+  for (int i = 0; i < nq; ++i) q3out[i] = z[M::ZQ[i]];
+  if (a.d.ok()) {
+#pragma unroll
+    for (int i = 0; i < nq; ++i) {
+      if (!a.d_skip_q2) a.d.at(i, b) = xin[nq + i];
+      a.d.at(nq + i, b) = q3out[i];
+    }
+  }
+  if (a.want_grad) {
+    if (a.dx.ok()) {   // constant blocks of fx: [0 I] on top, rows nq.. written by the sink
+#pragma unroll
+      for (int c = 0; c < n; ++c) {
+#pragma unroll
+        for (int i = 0; i < nq; ++i) a.dx.at(i + n * c, b) = (c == nq + i) ? T(1) : T(0);
+      }
+    }
+    if (a.du.ok()) {
+#pragma unroll
+      for (int c = 0; c < M::NU; ++c) {
+#pragma unroll
+        for (int i = 0; i < nq; ++i) a.du.at(i + n * c, b) = T(0);
+      }
+    }
+  }
+  if (a.status.ok()) a.status.at(0, b) = st;
+  if (a.iters.ok()) { a.iters.at(0, b) = it[0]; a.iters.at(1, b) = it[1]; }
+  return st;
+}
+
+template <class M, class T> OD_HD void unit_step_grad(const StepArgs<T>& a, long b) {
+  constexpr int nq = M::NQ, n = 2 * M::NQ;
+  T x[n], u[M::NU > 0 ? M::NU : 1], q3[nq];
+#pragma unroll
+  for (int i = 0; i < n; ++i) x[i] = a.x.at(i, b);
+#pragma unroll
+  for (int i = 0; i < M::NU; ++i) u[i] = a.u.at(i, b);
+  unit_step_core<M, T>(a, b, x, u, q3);
+}
+
+// ---- rollout: T sequential steps per trajectory, state carried in registers ------------------
+// problem index for per-knot outputs is (t*B + b): X has T+1 slots, the rest T slots.
+template <class T> struct RolloutArgs {
+  StepArgs<T> s;     // x = x1 (2nq per trajectory); u/d/dx/du/dq3/status/iters are per-knot views
+  View<T> x0;        // slot 0 of X (receives a copy of x1)
+  int Tn;
+};
+
+template <class M, class T> OD_HD void unit_rollout(const RolloutArgs<T>& ra, long b) {
+  constexpr int nq = M::NQ, n = 2 * M::NQ;
+  const StepArgs<T>& a = ra.s;
+  T x[n], u[M::NU > 0 ? M::NU : 1], q3[nq];
+#pragma unroll
+  for (int i = 0; i < n; ++i) x[i] = a.x.at(i, b);
+  if (ra.x0.ok()) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) ra.x0.at(i, b) = x[i];
+  }
+  for (int t = 0; t < ra.Tn; ++t) {
+    const long k = (long)t * a.B + b;
+#pragma unroll
+    for (int i = 0; i < M::NU; ++i) u[i] = a.u.at(i, k);
+    unit_step_core<M, T>(a, k, x, u, q3);
+#pragma unroll
+    for (int i = 0; i < nq; ++i) { x[i] = x[nq + i]; x[nq + i] = q3[i]; }
+  }
+}
+
+// ---- gradient bundle samples (src/gradient_bundle.jl:87-100) ---------------------------------
+// problem p = b*(N+1) + i : i = 0 nominal, i >= 1 perturbed by eta[:, i-1]; EVAL simulator, no grad.
+template <class T> struct BundleArgs {
+  StepArgs<T> s;          // x,u per knot b; outputs unused except opts/h/fric
+  int N;
+  const T* eta;           // (2nq+nu) x N col-major, shared by all knots
+  View<T> feta;           // nq per problem p
+  View<int> status;       // per problem p
+};
+
+template <class M, class T> OD_HD void unit_bundle_sample(const BundleArgs<T>& ba, long p) {
+  constexpr int nq = M::NQ, n = 2 * M::NQ, nzb = 2 * M::NQ + M::NU;
+  const StepArgs<T>& a = ba.s;
+  const long b = p / (ba.N + 1);
+  const int i = (int)(p - b * (ba.N + 1));
+  T x[n], u[M::NU > 0 ? M::NU : 1];
+#pragma unroll
+  for (int k = 0; k < n; ++k) x[k] = a.x.at(k, b) + (i > 0 ? ba.eta[k + nzb * (i - 1)] : T(0));
+#pragma unroll
+  for (int k = 0; k < M::NU; ++k) u[k] = a.u.at(k, b) + (i > 0 ? ba.eta[n + k + nzb * (i - 1)] : T(0));
+  T th[M::NTH], z[M::NZ];
+  mech_setup<M>(x, x + nq, u, a.fric, a.h, th, z);
+  struct NoSink { OD_HD void grad(int, int, T) {} } sink;
+  int it[2];
+  const int st = ip_step_grad<M>(a.opts, th, z, true, false, sink, it);
+#pragma unroll
+  for (int k = 0; k < nq; ++k) ba.feta.at(k, p) = z[M::ZQ[k]];
+  if (ba.status.ok()) ba.status.at(0, p) = st;
+}
+
+// ---- raw interior-point solve on user-supplied (z0, theta): rocket dynamics / projection ------
+// (src/models/rocket/dynamics.jl:101-210).  dz: NZQ x NGC col-major (rows ZQ, first NGC theta cols)
+template <class T> struct RawArgs {
+  long B;
+  Opts<T> opts;
+  View<const T> z0;   // NZ
+  View<const T> th;   // NTH
+  View<T> z;          // NZ (solution)
+  View<T> dz;         // NZQ*NGC
+  View<int> status, iters;
+  int want_grad;
+};
+
+template <class M, class T> struct RawSink {
+  const RawArgs<T>& a;
+  long b;
+  OD_HD void grad(int i, int c, T v) { if (a.dz.ok()) a.dz.at(i + M::NZQ * c, b) = v; }
+};
+
+template <class M, class T> OD_HD void unit_raw(const RawArgs<T>& a, long b) {
+  T th[M::NTH], z[M::NZ];
+#pragma unroll
+  for (int i = 0; i < M::NTH; ++i) th[i] = a.th.at(i, b);
+#pragma unroll
+  for (int i = 0; i < M::NZ; ++i) z[i] = a.z0.at(i, b);
+  RawSink<M, T> sink{a, b};
+  int it[2];
+  const int st = ip_step_grad<M>(a.opts, th, z, true, a.want_grad != 0, sink, it);
+#pragma unroll
+  for (int i = 0; i < M::NZ; ++i) a.z.at(i, b) = z[i];
+  if (a.status.ok()) a.status.at(0, b) = st;
+  if (a.iters.ok()) { a.iters.at(0, b) = it[0]; a.iters.at(1, b) = it[1]; }
+}
+
+// ---- rocket f / fx / fu with optional thrust-cone projection (dynamics.jl:101-268) -----------
+template <class T> struct RocketArgs {
+  long B;
+  T h, u_max;
+  Opts<T> opts_dyn, opts_proj;
+  int project;        // 0: f_rocket*, 1: f_rocket_proj*
+  int want_grad;
+  View<const T> x;    // 12
+  View<const T> u;    // 3
+  View<T> y;          // 12                      (f_rocket / f_rocket_proj)
+  View<T> dx;         // 12 x 12 col-major       (fx_*)
+  View<T> du;         // 12 x 3  col-major       (fu_*; projected: dz_dyn[:,u] * dproj[1:3,1:3])
+  View<T> uproj;      // 3 (projected control; optional)
+  View<int> status;   // bit0/1 dyn eval/grad ok, bit4/5 projection eval/grad ok
+};
+
+template <class MD, class MP, class T> OD_HD void unit_rocket(const RocketArgs<T>& a, long b) {
+  T x[12], u[3];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) x[i] = a.x.at(i, b);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) u[i] = a.u.at(i, b);
+  int st = 0;
+  T dproj[9];   // d uproj / d u  (3x3 col-major)
+  if (a.project) {
+    // soc_projection (dynamics.jl:168-186): z .= 0.1; z[3]+=1; z[10]+=1; z[7]=0; theta=[u; u_max]
+    T zp[MP::NZ], thp[MP::NTH];
+#pragma unroll
+    for (int i = 0; i < MP::NZ; ++i) zp[i] = T(MP::ZI_VAL[i]);
+    thp[0] = u[0]; thp[1] = u[1]; thp[2] = u[2]; thp[3] = a.u_max;
+    struct PSink {
+      T* d;
+      OD_HD void grad(int i, int c, T v) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[i + 3 * k] = (c == k) ? v : d[i + 3 * k];
+      }
+    } ps{dproj};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dproj[i] = T(0);
+    int itp[2];
+    const int sp_ = ip_step_grad<MP>(a.opts_proj, thp, zp, true, a.want_grad != 0, ps, itp);
+    st |= (sp_ & 3) << 4;
+    u[0] = zp[0]; u[1] = zp[1]; u[2] = zp[2];
+    if (a.uproj.ok()) { a.uproj.at(0, b) = u[0]; a.uproj.at(1, b) = u[1]; a.uproj.at(2, b) = u[2]; }
+  }
+  // f_rocket (dynamics.jl:101-114): z0 = x, theta = [x; u; h]
+  T th[MD::NTH], z[MD::NZ];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { th[i] = x[i]; z[i] = x[i]; }
+  th[12] = u[0]; th[13] = u[1]; th[14] = u[2]; th[15] = a.h;
+  // du with projection needs the 12x3 block times dproj: collect the u-columns in registers
+  T dyn_u[36];
+  struct DSink2 {
+    const RocketArgs<T>& a; long b; T* dyn_u;
+    OD_HD void grad(int i, int c, T v) {
+      if (c < 12) { if (a.dx.ok()) a.dx.at(i + 12 * c, b) = v; }
+      else {
+        // c - 12 in {0,1,2}; static unroll keeps dyn_u in registers
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dyn_u[i + 12 * k] = (c - 12 == k) ? v : dyn_u[i + 12 * k];
+      }
+    }
+  } ds{a, b, dyn_u};
+#pragma unroll
+  for (int i = 0; i < 36; ++i) dyn_u[i] = T(0);
+  int it[2];
+  const int sd = ip_step_grad<MD>(a.opts_dyn, th, z, true, a.want_grad != 0, ds, it);
+  st |= (sd & 7);
+  if (a.y.ok()) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) a.y.at(i, b) = z[i];
+  }
+  if (a.want_grad && a.du.ok()) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        T v;
+        if (a.project) {   // mul!(du, du_dyn_cache, du_proj_cache)  (dynamics.jl:264-267)
+          v = dyn_u[i] * dproj[3 * c] + dyn_u[i + 12] * dproj[1 + 3 * c] + dyn_u[i + 24] * dproj[2 + 3 * c];
+        } else {
+          v = dyn_u[i + 12 * c];
+        }
+        a.du.at(i + 12 * c, b) = v;
+      }
+    }
+  }
+  if (a.status.ok()) a.status.at(0, b) = st;
+}
+
+}  // namespace od

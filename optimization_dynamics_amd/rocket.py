@@ -1,0 +1,126 @@
+"""Host-side mirror of src/models/rocket/dynamics.jl: `RocketInfo` and the callbacks
+f_rocket / fx_rocket / fu_rocket and their thrust-cone-projected variants.
+
+One HIP lane per knot runs the SOCP projection (10-variable interior-point solve), the implicit-
+midpoint dynamics solve (12-variable Newton), both implicit gradients and the 12x3 * 3x3 chain
+product (mul!, dynamics.jl:264-267).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .dynamics import _ptr
+from .models import rocket as rocket_model
+
+
+class RocketInfo:
+    """RocketInfo(rocket, u_max, h, r, rz, rtheta, r_proj, rz_proj, rtheta_proj)
+    (dynamics.jl:13-99); residual functions are compiled into the library."""
+
+    def __init__(self, rocket=rocket_model, u_max=12.5, h=0.05, *, dtype=torch.float64, device="cuda",
+                 lib=None, options=None):
+        self.model = rocket
+        self.u_max = float(u_max)
+        self.h = float(h)
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.lib = lib if lib is not None else _lib.default_library()
+        o = self.lib.default_options("rocket_dynamics")      # dynamics.jl:21-27
+        if dtype == torch.float32:
+            # r_tol = 1e-8 is below fp32 resolution (eps ~ 6e-8 * |y|): rescaled, see DESIGN.md
+            o.r_tol = 2.0e-5
+        if options:
+            for k, v in options.items():
+                setattr(o, k, v)
+        self.options = o
+        hd = C.c_void_p()
+        od_dtype = _lib.OD_F64 if dtype == torch.float64 else _lib.OD_F32
+        self.lib.check(self.lib.cdll.od_create(_lib.MODEL_IDS["rocket_dynamics"], od_dtype, C.byref(o), self.h, C.byref(hd)))
+        self._h = hd
+        self.lib.check(self.lib.cdll.od_set_u_max(self._h, self.u_max))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.lib.cdll.od_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _use_current_stream(self):
+        if self.device.type == "cuda":
+            self.lib.check(self.lib.cdll.od_set_stream(self._h, torch.cuda.current_stream(self.device).cuda_stream))
+
+    def solve(self, X, U, project=False, grads=True):
+        """batched: X (12, B), U (3, B) -> Y (12,B), DX (12,12,B), DU (12,3,B), Uproj (3,B), status (B,)"""
+        self._use_current_stream()
+        X = X.to(device=self.device, dtype=self.dtype).contiguous()
+        U = U.to(device=self.device, dtype=self.dtype).contiguous()
+        B = X.shape[-1]
+        mk = lambda *s: torch.empty(*s, dtype=self.dtype, device=self.device)
+        Y = mk(12, B)
+        DX = mk(144, B) if grads else None
+        DU = mk(36, B) if grads else None
+        UP = mk(3, B) if project else None
+        st = torch.empty(B, dtype=torch.int32, device=self.device)
+        self.lib.check(self.lib.cdll.od_rocket(self._h, B, 1 if project else 0, _ptr(X), _ptr(U), _ptr(Y), _ptr(DX), _ptr(DU), _ptr(UP), _ptr(st)))
+        if grads:
+            DX = DX.view(12, 12, B).transpose(0, 1)
+            DU = DU.view(3, 12, B).transpose(0, 1)
+        return Y, DX, DU, UP, st
+
+
+def _scalar(info, x, u, project, grads):
+    X = torch.tensor(np.asarray(x, dtype=np.float64)).reshape(12, 1)
+    U = torch.tensor(np.asarray(u, dtype=np.float64)).reshape(3, 1)
+    Y, DX, DU, UP, st = info.solve(X, U, project=project, grads=grads)
+    return (Y[:, 0].double().cpu().numpy(),
+            None if DX is None else DX[:, :, 0].double().cpu().numpy(),
+            None if DU is None else DU[:, :, 0].double().cpu().numpy())
+
+
+def f_rocket(d, info: RocketInfo, x, u, w=None):
+    """dynamics.jl:101-114"""
+    d[...] = _scalar(info, x, u, False, False)[0]
+    return d
+
+
+def fx_rocket(dx, info: RocketInfo, x, u, w=None):
+    """dynamics.jl:134-148"""
+    dx[...] = _scalar(info, x, u, False, True)[1]
+    return dx
+
+
+def fu_rocket(du, info: RocketInfo, x, u, w=None):
+    """dynamics.jl:150-164"""
+    du[...] = _scalar(info, x, u, False, True)[2]
+    return du
+
+
+def f_rocket_proj(d, info: RocketInfo, x, u, w=None):
+    """dynamics.jl:215-228"""
+    d[...] = _scalar(info, x, u, True, False)[0]
+    return d
+
+
+def fx_rocket_proj(dx, info: RocketInfo, x, u, w=None):
+    """dynamics.jl:239-252"""
+    dx[...] = _scalar(info, x, u, True, True)[1]
+    return dx
+
+
+def fu_rocket_proj(du, info: RocketInfo, x, u, w=None):
+    """dynamics.jl:254-268"""
+    du[...] = _scalar(info, x, u, True, True)[2]
+    return du
+
+
+def soc_projection(x, info: RocketInfo):
+    """dynamics.jl:168-186: Euclidean projection of x onto {|u_1:2| <= u_3, 0 <= u_3 <= u_max}
+    (interior-point solution at kappa_tol = 1e-4)."""
+    X = torch.zeros(12, 1, dtype=torch.float64)
+    U = torch.tensor(np.asarray(x, dtype=np.float64)).reshape(3, 1)
+    _, _, _, UP, _ = info.solve(X, U, project=True, grads=False)
+    return UP[:, 0].double().cpu().numpy()
