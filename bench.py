@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""Headline benchmark: contact-implicit steps + implicit gradients per second,
+hopper, T=100, batch=4096 rollouts per GPU (BASELINE.json metric).
+
+One "step" = one od_rollout launch: 4096 trajectories x 100 knots = 409 600 units, each unit =
+(q1,q2,u) -> (q3, dq3/dq1, dq3/dq2, dq3/du) honouring kappa_eval for the state and kappa_grad for
+the gradient (the reference's f + fx + fu, src/dynamics.jl:81-128).  Inputs are resident in HBM
+before the timed region.  Multi-GPU: one process per GPU (torchrun), trajectories sharded, no
+data-path collective (weak scaling: 4096 rollouts per GPU); --gather adds the all-gather of the
+linearisation (x+, A, B) that an outer iLQR backward pass would consume.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector == fp64 matrix peak
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md
+HOPPER = dict(nq=4, nu=2, nz=20, nth=13)
+
+
+def algorithmic_flops_per_unit(iters_eval, stats):
+    """F = I_e (F_rz + 2/3 nz^3 + 4 nz^2 + 2 F_r + c_cone) + (F_rz + F_rth + 2/3 nz^3 + 2 nz^2 nth)
+    = the reference's dense-LU algorithm, with the measured mean iteration count I_e."""
+    nz, nth = HOPPER["nz"], HOPPER["nth"]
+    F_r, F_rz, F_rth = stats["ops_r"], stats["ops_rz"], stats["ops_rth"]
+    c_cone = 100.0
+    per_iter = F_rz + (2.0 / 3.0) * nz ** 3 + 4.0 * nz ** 2 + 2.0 * F_r + c_cone
+    grad = F_rz + F_rth + (2.0 / 3.0) * nz ** 3 + 2.0 * nz ** 2 * nth
+    return iters_eval * per_iter + grad, per_iter, grad
+
+
+def algorithmic_bytes_per_unit():
+    nq, nu = HOPPER["nq"], HOPPER["nu"]
+    return 8 * ((2 * nq + nu) + nq + nq * (2 * nq + nu))     # 432 B
+
+
+def make_inputs(batch, horizon, seed, h=0.05):
+    """q = [0, 0.5 + r_foot, 0, 0.5] + N(0, 0.02^2), x1 = [q; q];
+    u_t = [0; g m_body h/2] + N(0,1) (examples/hopper.jl:178,270)."""
+    rng = np.random.default_rng(seed)
+    q = np.array([0.0, 0.5 + 0.05, 0.0, 0.5])[:, None] + rng.normal(0.0, 0.02, (4, batch))
+    x1 = np.vstack([q, q])
+    U = np.array([0.0, 9.81 * 3.0 * 0.5 * h])[:, None, None] + rng.normal(0.0, 1.0, (2, horizon, batch))
+    return x1, U
+
+
+def cpu_baseline(batch, horizon, seed, budget_s=12.0):
+    """Oracle (CPU restatement: three dense-LU solves per knot like the reference) on a bounded
+    sample of the same workload, OpenMP over trajectories on all host cores."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    sim = O.make_sim("hopper", 0.05, kappa_tol=1e-4, kappa_grad_tol=1e-3)
+    x1, U = make_inputs(batch, horizon, seed)
+    nb = min(batch, max(cores, 16))
+    t0 = time.time()
+    O.rollout(sim, x1[:, :nb], U[:, :, :nb])
+    dt = time.time() - t0
+    rate = nb * horizon / dt
+    nb2 = int(min(batch, max(nb, rate * budget_s / horizon)))
+    nb2 = max(cores, (nb2 // cores) * cores)
+    t0 = time.time()
+    _, _, _, bad = O.rollout(sim, x1[:, :nb2], U[:, :, :nb2])
+    dt = time.time() - t0
+    return dict(value=nb2 * horizon / dt, unit="steps+grads/s", cores=cores, kind="port",
+                sample="%d of %d trajectories x T=%d (same seed), %.1f s, OpenMP over trajectories; "
+                       "CPU restatement of the reference algorithm (f, fx, fu = 3 dense-LU IP solves per knot), "
+                       "not the Julia reference" % (nb2, batch, horizon, dt),
+                nonconverged_solves=int(bad))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4096, help="rollouts per GPU")
+    ap.add_argument("--horizon", type=int, default=100)
+    ap.add_argument("--gather", action="store_true", help="all-gather (x+, A, B) after every step (RCCL)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path in the product library)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from optimization_dynamics_amd import ImplicitDynamics, hopper
+    im = ImplicitDynamics(hopper, 0.05, r_tol=1e-8, kappa_eval_tol=1e-4, kappa_grad_tol=1e-3, device=dev)  # examples/hopper.jl:42
+    B, T = args.batch, args.horizon
+    x1, U = make_inputs(B, T, seed=rank)
+    x1d = torch.tensor(x1, device=dev)
+    Ud = torch.tensor(U, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    out = None
+    gather_bufs = None
+
+    def step():
+        nonlocal out, gather_bufs
+        X, A, Bm, st, it, out = im.rollout(x1d, Ud, out=out)
+        if args.gather and world > 1:
+            if gather_bufs is None:
+                gather_bufs = [torch.empty(world * t.numel(), dtype=t.dtype, device=dev) for t in (out["X"], out["A"], out["Bm"])]
+            for buf, t in zip(gather_bufs, (out["X"], out["A"], out["Bm"])):
+                dist.all_gather_into_tensor(buf, t.reshape(-1))
+        return st, it
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)      # the rollout kernel is launched on this (torch current) stream
+        st, it = step()
+        ev[k][1].record(stream)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    units_per_rank = B * T
+    value = world * units_per_rank * args.steps / elapsed
+    stc = torch.bincount(st.flatten(), minlength=8).tolist()
+    it_eval = float(it[0].double().mean().item())
+    it_max = int(it.max().item())
+
+    if rank == 0:
+        stats = json.load(open(os.path.join(ROOT, "optimization_dynamics_amd", "csrc", "gen", "stats.json")))["hopper"]
+        F, per_iter, grad = algorithmic_flops_per_unit(it_eval, stats)
+        ach_tflops = F * units_per_rank / (kernel_ms * 1e-3) / 1e12
+        ach_gbs = algorithmic_bytes_per_unit() * units_per_rank / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "contact-implicit steps+grads/sec, hopper T=100 batch=4096",
+            "value": value, "unit": "steps+grads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "hopper (RoboDojo path-following contact), T=%d, batch=%d rollouts per GPU, "
+                                   "h=0.05, kappa_eval=1e-4, kappa_grad=1e-3, r_tol=1e-8; od_rollout = f+fx+fu per knot" % (T, B),
+                       "units_per_step_per_gpu": units_per_rank, "parallelism": "rollouts sharded x%d, no collective%s" % (world, " + all-gather(x+,A,B)" if args.gather else "")},
+            "roofline": {"bound": "mfma", "bound_detail": "fp64 compute roof (FP64 vector = FP64 matrix peak on MI355X); no MFMA-shaped work on this path",
+                         "achieved": ach_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / FP64_PEAK_TFLOPS,
+                         "traffic": None,
+                         "kernel": "k_rollout<Model_hopper,double>", "kernel_ms": kernel_ms,
+                         "algorithmic_flops_per_unit": F, "mean_iterations_to_kappa_eval": it_eval, "max_iterations": it_max,
+                         "hbm_algorithmic_GBps": ach_gbs, "hbm_frac": ach_gbs / HBM_PEAK_GBS},
+            "solver_status_counts": {"converged(7)": stc[7], "other": int(sum(stc) - stc[7])},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline(B, T, seed=0)
+            except Exception as e:   # the oracle is a reported baseline, never a dependency of the timed path
+                line["cpu_baseline"] = {"value": None, "unit": "steps+grads/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

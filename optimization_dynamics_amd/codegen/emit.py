@@ -231,7 +231,7 @@ class _Elim:
     """Static-order sparse Gaussian elimination on the structural pattern of rz, preceded by
     runtime row/column role swaps for the second-order-cone blocks, followed by a dense tail."""
 
-    def __init__(self, nz, pattern, order, floor_pivots=(), swaps=()):
+    def __init__(self, nz, pattern, order, floor_pivots=(), swaps=(), tail_last=()):
         self.nz = nz
         self.order = list(order)
         self.swaps = list(swaps)
@@ -298,7 +298,12 @@ class _Elim:
             self.fwd.append((pr, fw))
             self.bwd.append((pr, pc, ip, us))
         self.tail_rows = rows
-        self.tail_cols = cols
+        # dense tail: cone leftovers first, configuration unknowns last.  In sticking / statically
+        # indeterminate contact modes the leftover columns carry information only at the scale of the
+        # vanishing cone variables (~1e-18); eliminating them before they are mixed with the O(1)
+        # configuration block keeps that scale intact (same effect as the reference's full partial
+        # pivoting), see DESIGN.md "KKT elimination".
+        self.tail_cols = [c for c in cols if c not in tail_last] + [c for c in cols if c in tail_last]
         self.m = len(rows)
         self.tail_base = self.slots
         self.slots += self.m * self.m
@@ -324,7 +329,7 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
     def S(e):
         return e.subs(sub, simultaneous=True)
 
-    el = _Elim(m.nz, d.rz_nz, m.elim, set(m.floor_pivots), m.swaps)
+    el = _Elim(m.nz, d.rz_nz, m.elim, set(m.floor_pivots), m.swaps, set(m.idx_zq) if (m.soc and m.kind == 'mech') else ())
     nnz = len(d.rz_nz)
     nnzth = len(d.rth_nz)
 

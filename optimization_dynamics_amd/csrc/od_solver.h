@@ -14,6 +14,14 @@
 #pragma once
 #include "od_math.h"
 
+#ifdef OD_TRACE   // test-harness builds only (tests/host_emu): per-iteration trace to stdout
+#include <cstdio>
+extern int od_trace_flag;
+#define OD_TRACE_IT(...) do { if (od_trace_flag) std::printf(__VA_ARGS__); } while (0)
+#else
+#define OD_TRACE_IT(...)
+#endif
+
 namespace od {
 
 template <class T> struct Opts {
@@ -228,6 +236,7 @@ OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, boo
     for (int i = 0; i < M::NZ; ++i) z[i] = zc[i];
     r_vio = r_c;
     k_vio = k_c;
+    OD_TRACE_IT("dev it %d alpha %.17g r_vio %.6e k_vio %.6e\n", it + 1, (double)alpha, (double)r_vio, (double)k_vio);
   }
   if (want_state) {
 #pragma unroll

@@ -17,6 +17,10 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
+
+int od_oracle_trace = 0;   /* tests can switch on a per-iteration trace */
+void od_oracle_set_trace(int v) { od_oracle_trace = v; }
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -262,6 +266,7 @@ int od_oracle_ip_solve(int model_id, const od_oracle_opts* o, double kappa_tol, 
     memcpy(z, zc, sizeof(double) * nz);
     r_vio = r_c;
     k_vio = k_c;
+    if (od_oracle_trace) printf("ora it %d alpha %.17g r_vio %.6e k_vio %.6e\n", iters, alpha, r_vio, k_vio);
   }
   if (iters_out) *iters_out = iters;
   int status = (r_vio < o->r_tol && k_vio < kappa_tol) ? 1 : 0;   /* NaN -> 0 */

@@ -1,0 +1,81 @@
+"""The C-ABI library loads and exports every symbol include/od_mi355x.h declares (CPU tier: no
+compute calls), and the product path fails loudly without its HIP extension / without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "od_mi355x.h")
+SO = os.path.join(ROOT, "optimization_dynamics_amd", "libod_mi355x.so")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(od_[a-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not os.path.exists(SO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "optimization_dynamics_amd", "csrc"), "-j", "8"])
+    return SO
+
+
+def test_header_symbols_all_exported(built):
+    syms = declared_symbols()
+    assert len(syms) >= 25 and "od_rollout" in syms and "od_bundle_grad" in syms
+    lib = C.CDLL(built)
+    for s in syms:
+        assert hasattr(lib, s), "missing export: " + s
+
+
+def test_python_binding_covers_header():
+    from optimization_dynamics_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_model_table_without_gpu(built):
+    from optimization_dynamics_amd import _lib
+    lib = _lib.Library(built)
+    assert lib.model_dims("hopper") == dict(nq=4, nu=2, nz=20, ntheta=13, nfric=2)
+    assert lib.model_dims("planar_push") == dict(nq=5, nu=2, nz=35, ntheta=13, nfric=0)
+    assert lib.model_dims("rocket_dynamics")["nz"] == 12 and lib.model_dims("rocket_projection")["nz"] == 10
+    assert lib.raw_grad_dims("rocket_dynamics") == (12, 15)
+    o = lib.default_options("hopper")
+    assert o.r_tol == 1e-8 and o.kappa_eval_tol == 1e-4 and o.kappa_grad_tol == 1e-3 and o.max_ls == 25
+    assert lib.cdll.od_model_name(7) == b"hopper"
+    assert lib.cdll.od_version() >= 100
+
+
+def test_fails_loudly_without_device(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from optimization_dynamics_amd import _lib
+    lib = _lib.Library(built)
+    h = C.c_void_p()
+    rc = lib.cdll.od_create(7, 0, None, 0.05, C.byref(h))
+    assert rc == -4 and b"no CPU path" in lib.cdll.od_last_error()
+    with pytest.raises(_lib.ODError):
+        lib.check(rc)
+
+
+def test_fails_loudly_without_extension(tmp_path):
+    from optimization_dynamics_amd import _lib
+    with pytest.raises(_lib.ODError, match="no CPU fallback"):
+        _lib.Library(str(tmp_path / "libod_mi355x.so"))
+
+
+def test_product_never_imports_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/"""
+    pkg = os.path.join(ROOT, "optimization_dynamics_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".h", ".hip", ".inc", ".cpp")) and "codegen" not in dp:
+                txt = open(os.path.join(dp, f)).read()
+                for pat in ("from oracle", "import oracle", "libod_oracle", "oracle/", "od_oracle_"):
+                    assert pat not in txt, (pat, os.path.join(dp, f))

@@ -1,0 +1,102 @@
+"""CPU tier: the product's device code + C ABI compiled for the host (tests/host_emu, a test
+harness: stand-in hip_runtime.h that runs each lane as a loop iteration) against the oracle.
+Checks the solver logic (static sparse KKT elimination vs the oracle's dense partial-pivot LU,
+fused kappa_eval/kappa_grad prefix loop) and all host-side plumbing without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+import parity_checks as P
+import workloads as W
+
+MECH = ["acrobot_impact", "acrobot_nominal", "cartpole_friction", "cartpole_frictionless", "hopper", "planar_push"]
+
+
+@pytest.mark.parametrize("name", MECH)
+def test_step_grad_parity(oracle, emu_lib, name):
+    P.check_step_grad(oracle, emu_lib, "cpu", name, 512 if name != "planar_push" else 256)
+
+
+@pytest.mark.parametrize("name", ["acrobot_impact", "hopper"])
+def test_step_and_compact_outputs_consistent(emu_lib, name):
+    P.check_step_only_and_compact(emu_lib, "cpu", name, 64)
+
+
+@pytest.mark.parametrize("name", ["cartpole_friction", "hopper"])
+def test_batch_major_layout_identical(emu_lib, name):
+    P.check_layouts(emu_lib, "cpu", name, 96)
+
+
+def test_hopper_rollout_parity(oracle, emu_lib):
+    P.check_rollout(oracle, emu_lib, "cpu", 48, 30)
+
+
+def test_cartpole_plumbing_config_single_rollout(oracle, emu_lib):
+    """BASELINE config 1: cartpole with joint friction, T=51, single rollout, x1 = 0, u_1 = -1.5
+    (examples/cartpole.jl:15-21,41-46,78)."""
+    im = P.make_im("cartpole_friction", emu_lib, "cpu")
+    T = 50
+    U = np.zeros((1, T, 1)); U[0, 0, 0] = -1.5
+    X, A, Bm, st, it, _ = im.rollout(torch.zeros(4, 1, dtype=torch.float64), torch.tensor(U))
+    Xo, Ao, Bo, bad = oracle.rollout(P.make_sim(oracle, "cartpole_friction"), np.zeros((4, 1)), U)
+    assert bad == 0 and ((st.numpy() & 3) == 3).all()
+    assert np.abs(X.numpy() - Xo).max() < 1e-9
+    assert W.grad_rel_err(A.numpy().reshape(16, T), Ao.reshape(16, T)).max() < 1e-6
+
+
+@pytest.mark.parametrize("name,N", [("planar_push", 64), ("hopper", 50)])
+def test_gradient_bundle(oracle, emu_lib, name, N):
+    P.check_bundle(oracle, emu_lib, "cpu", name, 6, N)
+
+
+def test_ls_known_answer_on_device_kernel(emu_lib):
+    P.check_ls_kat(emu_lib, "cpu")
+
+
+def test_rocket_f64(oracle, emu_lib):
+    P.check_rocket(oracle, emu_lib, "cpu", 32)
+
+
+def test_rocket_f32(oracle, emu_lib):
+    P.check_rocket(oracle, emu_lib, "cpu", 16, dtype=torch.float32)
+
+
+@pytest.mark.parametrize("name", ["acrobot_impact", "cartpole_friction"])
+def test_reference_signature_callbacks(oracle, emu_lib, name):
+    P.check_scalar_callbacks(oracle, emu_lib, "cpu", name)
+
+
+def test_finite_undercut_runs_two_passes(oracle, emu_lib):
+    """with cones and a finite undercut the centering floor depends on kappa_tol: the eval and grad
+    simulators are no longer prefix-related and the library must run them separately"""
+    name = "acrobot_impact"
+    X, U = W.knots(name, 64, seed=61)
+    im = P.make_im(name, emu_lib, "cpu", options=dict(undercut=5.0))
+    D, DX, DU, st, it = im.step_grad(torch.tensor(X), torch.tensor(U))
+    Do, DXo, DUo, bad = oracle.step_grad_batch(P.make_sim(oracle, name, undercut=5.0), X, U)
+    assert np.abs(D.numpy() - Do).max() < 1e-6
+    rel = W.grad_rel_err(np.concatenate([DX.numpy(), DU.numpy()], 1), np.concatenate([DXo, DUo], 1))
+    assert np.median(rel) < 1e-9 and (rel < 1e-4).mean() > 0.98
+
+
+def test_friction_vector_is_live(emu_lib):
+    """cartpole_friction.friction .= [...] after construction must take effect (examples/cartpole.jl:21)"""
+    from optimization_dynamics_amd import models
+    im = P.make_im("cartpole_friction", emu_lib, "cpu")
+    X, U = W.knots("cartpole_friction", 8, seed=71)
+    D1, _, _ = im.step(torch.tensor(X), torch.tensor(U))
+    models.cartpole_friction.friction[:] = [0.0, 0.0]
+    D2, _, _ = im.step(torch.tensor(X), torch.tensor(U))
+    models.cartpole_friction.friction[:] = [0.35, 0.35]
+    assert not torch.equal(D1, D2)
+
+
+def test_empty_batch_and_bad_arguments(emu_lib):
+    import ctypes as C
+    im = P.make_im("hopper", emu_lib, "cpu")
+    assert emu_lib.cdll.od_step(im._h, 0, 0, 0, 0, 0, 0) == 0          # empty batch is a no-op
+    assert emu_lib.cdll.od_step(im._h, 4, 0, 0, 0, 0, 0) == -1         # null input
+    assert b"null input" in emu_lib.cdll.od_last_error()
+    assert emu_lib.cdll.od_rocket(im._h, 4, 0, 1, 1, 0, 0, 0, 0, 0) == -2   # wrong model
+    fr = (C.c_double * 3)(0.1, 0.2, 0.3)
+    assert emu_lib.cdll.od_set_friction(im._h, fr, 3) == -1
