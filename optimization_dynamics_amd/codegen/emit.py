@@ -80,7 +80,7 @@ class _DevicePrinter(C99CodePrinter):
 def _cse_block(exprs: Sequence[sp.Expr], printer, scalar: str, prefix: str) -> Tuple[List[str], List[str]]:
     """CSE the expressions; returns (statement lines, printed result expressions)."""
     syms = sp.numbered_symbols(prefix)
-    repl, red = sp.cse(list(exprs), symbols=syms, optimizations="basic")
+    repl, red = sp.cse(list(exprs), symbols=syms)
     lines = []
     for s, e in repl:
         lines.append("const %s %s = %s;" % (scalar, s.name, printer.doprint(e)))
@@ -89,7 +89,7 @@ def _cse_block(exprs: Sequence[sp.Expr], printer, scalar: str, prefix: str) -> T
 
 
 def count_ops(exprs: Sequence[sp.Expr]) -> int:
-    repl, red = sp.cse(list(exprs), optimizations="basic")
+    repl, red = sp.cse(list(exprs))
     return int(sum(sp.count_ops(e) for _, e in repl) + sum(sp.count_ops(e) for e in red))
 
 
@@ -158,11 +158,8 @@ def emit_oracle(m: ModelSpec, d: Derived) -> str:
             o.write("  %s[%d] = %s;\n" % (outname, idx, e))
         o.write("}\n\n")
 
-    sub = {s: sp.Symbol("z[%d]" % i) for i, s in enumerate(m.z)}
-    sub.update({s: sp.Symbol("th[%d]" % i) for i, s in enumerate(m.th)})
-
     def S(e):
-        return e.subs(sub, simultaneous=True)
+        return e
 
     func("%s_r(const double* z, const double* th, double kappa, double* r)" % n,
          [S(e) for e in d.r], "r")
@@ -271,9 +268,9 @@ class _Elim:
             cols.remove(pc)
             ip = self._slot()
             if (pr, pc) in floor_pivots:
-                L.append("{ const T ip_ = T(1) / od_max(a_%d_%d, T(OD_PIVOT_FLOOR)); f.v[%d] = ip_;" % (pr, pc, ip))
+                L.append("{ const T ip_ = od_rcp(od_max(a_%d_%d, T(OD_PIVOT_FLOOR))); f.v[%d] = ip_;" % (pr, pc, ip))
             else:
-                L.append("{ const T ip_ = T(1) / a_%d_%d; f.v[%d] = ip_;" % (pr, pc, ip))
+                L.append("{ const T ip_ = od_rcp(a_%d_%d); f.v[%d] = ip_;" % (pr, pc, ip))
             fw = []
             prow = [j for j in cols if (pr, j) in pat]
             for i in rows:
@@ -322,12 +319,6 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
     o.write("// GENERATED by optimization_dynamics_amd.codegen (device flavour) -- do not edit.\n")
     o.write("// Model %s: nz=%d ntheta=%d  (reference residual statement: see codegen/models.py)\n" % (n, m.nz, m.nth))
     o.write("#pragma once\n#include \"../od_math.h\"\n\nnamespace od {\n\n")
-
-    sub = {s: sp.Symbol("z[%d]" % i) for i, s in enumerate(m.z)}
-    sub.update({s: sp.Symbol("th[%d]" % i) for i, s in enumerate(m.th)})
-
-    def S(e):
-        return e.subs(sub, simultaneous=True)
 
     el = _Elim(m.nz, d.rz_nz, m.elim, set(m.floor_pivots), m.swaps, set(m.idx_zq) if (m.soc and m.kind == 'mech') else ())
     nnz = len(d.rz_nz)
@@ -382,24 +373,151 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
     o.write("  static constexpr int DEF_MAX_ITER = %d, DEF_MAX_LS = %d;\n" % (op["max_iter"], op["max_ls"]))
     o.write('  static constexpr const char* NAME = "%s";\n\n' % n)
 
-    def func(sig, exprs, outs_spec, prefix):
-        """outs_spec: list of (array name, index) aligned with exprs."""
-        o.write("  template <class T> OD_HD static void %s {\n" % sig)
-        lines, outs = _cse_block(exprs, pr, "T", prefix)
-        for ln in lines:
-            o.write("    " + ln + "\n")
-        for (an, idx), e in zip(outs_spec, outs):
-            o.write("    %s[%d] = %s;\n" % (an, idx, e))
-        o.write("  }\n\n")
+    # ---- staged evaluation --------------------------------------------------------------------
+    # One joint CSE over r(z;theta,0), the nonzeros of rz and of rtheta.  Temporaries are split into
+    #   * theta-only ("pre"):   computed once per problem by eval_pre (the q0/q1 half of the discrete
+    #                           Euler-Lagrange residual, 1/h, ... are loop invariants of the IP loop)
+    #   * trigonometric, z-dependent ("tr"): computed by eval_r at the point it is called on and
+    #                           re-used by eval_rz / eval_rth at the same point (the Jacobian is always
+    #                           evaluated at the last accepted line-search candidate)
+    #   * everything else: recomputed inside the function that needs it.
+    r0 = list(d.r0)
+    rzv = [d.rz[i, j] for (i, j) in d.rz_nz]
+    rthv = [d.rth[i, j] for (i, j) in d.rth_nz]
+    # split every residual row into its theta-only addends (one stored value per row: e.g. the
+    # (q0, q1) half of the discrete Euler-Lagrange equations) and the z-dependent rest
+    row_pre = []          # (symbol, theta-only expression)
+    r_loop = []
+    for i, e in enumerate(r0):
+        indep, dep = e.as_independent(*m.z, as_Add=True)
+        if sp.count_ops(indep) >= 2:
+            ps = sp.Symbol("pq%d" % i, real=True)
+            row_pre.append((ps, indep))
+            r_loop.append(ps + dep)
+        else:
+            r_loop.append(e)
+    npre_rows = len(row_pre)
+    repl, red = sp.cse([e for _, e in row_pre] + r_loop + rzv + rthv, symbols=sp.numbered_symbols("x"))
+    red_rowpre = red[:npre_rows]
+    red = red[npre_rows:]
+    red_r, red_rz, red_rth = red[:m.nz], red[m.nz:m.nz + nnz], red[m.nz + nnz:]
+    zs = set(m.z)
+    ortv = {m.z[i] for i in (set(m.ort[0]) | set(m.ort[1]))}
+    tdef = {sy: e for sy, e in repl}
+    dep_z, dep_ort = {}, {}
+    for sy, e in repl:
+        fs = e.free_symbols
+        dep_z[sy] = any((f in zs) or dep_z.get(f, False) for f in fs)
+        dep_ort[sy] = any((f in ortv) or dep_ort.get(f, False) for f in fs)
+    is_trig = {sy: (dep_z[sy] and isinstance(e, (sp.sin, sp.cos))) for sy, e in repl}
+    for sy in tdef:
+        if is_trig[sy]:
+            assert not dep_ort[sy], "trig of a clamped (orthant) variable cannot be shared between r and rz"
 
-    r0 = [S(e) for e in d.r0]
-    rzv = [S(d.rz[i, j]) for (i, j) in d.rz_nz]
-    rthv = [S(d.rth[i, j]) for (i, j) in d.rth_nz]
-    func("eval_r(const T* z, const T* th, T* r)", r0, [("r", i) for i in range(m.nz)], "x")
-    func("eval_rz(const T* z, const T* th, T* a)", rzv, [("a", k) for k in range(nnz)], "x")
-    func("eval_r_rz(const T* z, const T* th, T* r, T* a)", r0 + rzv,
-         [("r", i) for i in range(m.nz)] + [("a", k) for k in range(nnz)], "x")
-    func("eval_rth(const T* z, const T* th, T* g)", rthv, [("g", k) for k in range(nnzth)], "x")
+    def closure(exprs):
+        need, stack = set(), [f for e in exprs for f in e.free_symbols if f in tdef]
+        while stack:
+            t = stack.pop()
+            if t in need:
+                continue
+            need.add(t)
+            stack += [f for f in tdef[t].free_symbols if f in tdef]
+        return need
+
+    need_any = closure(list(red_r) + list(red_rz) + list(red_rth))
+    trig_all = [sy for sy, _ in repl if is_trig[sy] and sy in need_any]
+    # theta-only temporaries: the expensive ones are computed once (eval_pre -> pre[]), the cheap ones
+    # (a couple of flops) are recomputed where needed -- every stored value pins two VGPRs for the whole
+    # interior-point loop.
+    PRE_THRESH = 16
+
+    def _w(e):
+        c = int(sp.count_ops(e))
+        c += 20 * len(e.atoms(sp.sin, sp.cos))
+        c += 3 * sum(1 for p_ in e.atoms(sp.Pow) if p_.exp.is_negative)
+        return c
+
+    full_cost = {}
+    for sy, e in repl:
+        if not dep_z[sy]:
+            full_cost[sy] = _w(e) + sum(full_cost[f] for f in e.free_symbols if f in full_cost)
+    stored = {sy for sy in full_cost if full_cost[sy] >= PRE_THRESH}
+    order = {sy: k for k, (sy, _) in enumerate(repl)}
+
+    def consumer_need(outs, through_trig=False):
+        """temporaries a function must compute itself: stop at stored theta-only values (pre[]) and,
+        unless it is the producer, at shared trig values (tr[])"""
+        need, stack = set(), [f for e in outs for f in e.free_symbols if f in tdef]
+        while stack:
+            t = stack.pop()
+            if t in need:
+                continue
+            need.add(t)
+            if t in stored or (is_trig[t] and not through_trig):
+                continue
+            stack += [f for f in tdef[t].free_symbols if f in tdef]
+        return need
+
+    need_r = consumer_need(list(red_r) + [tdef[t] for t in trig_all] + list(trig_all), through_trig=True)
+    need_rz2 = consumer_need(red_rz)
+    # only the loop functions (r, rz) justify pinning registers; rtheta is evaluated once per problem
+    # and recomputes whatever theta-only values r/rz did not ask for
+    stored = {t for n_ in (need_r, need_rz2) for t in n_ if t in stored}
+    need_rth2 = consumer_need(red_rth)
+    pre_live = sorted(stored, key=lambda t: order[t])
+    pre_idx = {t: k for k, t in enumerate(pre_live)}
+    row_idx = {ps: len(pre_live) + k for k, (ps, _) in enumerate(row_pre)}
+    tr_idx = {t: k for k, t in enumerate(trig_all)}
+    pre_need = closure([tdef[t] for t in pre_live] + list(red_rowpre)) | set(pre_live)
+
+    o.write("  static constexpr int NPRE = %d, NTR = %d;\n\n" % (max(1, len(pre_live) + npre_rows), max(1, len(trig_all))))
+    o.write("  // theta-only work, once per problem: expensive shared subexpressions + the theta-only addends of each residual row\n")
+    o.write("  template <class T> OD_HD static void eval_pre(const T* th, T* pre) {\n")
+    for sy, e in repl:
+        if sy in pre_need:
+            o.write("    const T %s = %s;\n" % (sy.name, pr.doprint(e)))
+    for t in pre_live:
+        o.write("    pre[%d] = %s;\n" % (pre_idx[t], t.name))
+    for (ps, _), e in zip(row_pre, red_rowpre):
+        o.write("    pre[%d] = %s;\n" % (row_idx[ps], pr.doprint(e)))
+    o.write("  }\n\n")
+
+    def body(need, outs, out_name, produce_trig):
+        rows_used = sorted({f for e in outs for f in e.free_symbols if f in row_idx}, key=lambda t: row_idx[t])
+        for ps in rows_used:
+            o.write("    const T %s = pre[%d];\n" % (ps.name, row_idx[ps]))
+        for sy, e in repl:
+            if sy not in need:
+                continue
+            if sy in stored:
+                o.write("    const T %s = pre[%d];\n" % (sy.name, pre_idx[sy]))
+            elif is_trig[sy] and not produce_trig:
+                o.write("    const T %s = tr[%d];\n" % (sy.name, tr_idx[sy]))
+            else:
+                o.write("    const T %s = %s;\n" % (sy.name, pr.doprint(e)))
+                if is_trig[sy]:
+                    o.write("    tr[%d] = %s;\n" % (tr_idx[sy], sy.name))
+        for k, e in enumerate(outs):
+            o.write("    %s[%d] = %s;\n" % (out_name, k, pr.doprint(e)))
+
+    o.write("  // r(z; theta, kappa = 0); also produces the shared trigonometric values tr[] at z\n")
+    o.write("  template <class T> OD_HD static void eval_r(const T* z, const T* th, const T* pre, T* tr, T* r) {\n")
+    body(need_r, red_r, "r", True)
+    o.write("  }\n\n")
+    o.write("  // structural nonzeros of rz at z (orthant variables possibly clamped); tr[] from eval_r at the same point\n")
+    o.write("  template <class T> OD_HD static void eval_rz(const T* z, const T* th, const T* pre, const T* tr, T* a) {\n")
+    body(need_rz2, red_rz, "a", False)
+    o.write("  }\n\n")
+    o.write("  template <class T> OD_HD static void eval_rth(const T* z, const T* th, const T* pre, const T* tr, T* g) {\n")
+    body(need_rth2, red_rth, "g", False)
+    o.write("  }\n\n")
+    def _loop_ops(need, outs):
+        return int(sum(sp.count_ops(tdef[t]) for t in need if t not in stored and not (is_trig[t] and need is not need_r))
+                   + sum(sp.count_ops(e) for e in outs))
+
+    d.stage_stats = dict(ops_pre=int(sum(sp.count_ops(tdef[t]) for t in pre_need)),
+                         ops_r_loop=_loop_ops(need_r, red_r), ops_rz_loop=_loop_ops(need_rz2, red_rz),
+                         ops_rth_loop=_loop_ops(need_rth2, red_rth), n_pre=len(pre_live) + npre_rows, n_trig=len(trig_all))
 
     # ---- factor ----
     o.write("  template <class T> struct Fact { T v[NFACT > 0 ? NFACT : 1]; int piv[MTAIL > 0 ? MTAIL : 1]; bool sw[NSWAP > 0 ? NSWAP : 1]; };\n\n")
@@ -465,7 +583,8 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
 
 
 def stats(m: ModelSpec, d: Derived) -> Dict[str, int]:
-    return dict(
+    extra = getattr(d, "stage_stats", {})
+    return dict(extra, 
         nz=m.nz, nth=m.nth, nnz_rz=len(d.rz_nz), nnz_rth=len(d.rth_nz),
         ops_r=count_ops(list(d.r0)), ops_rz=count_ops([d.rz[i, j] for (i, j) in d.rz_nz]),
         ops_r_rz=count_ops(list(d.r0) + [d.rz[i, j] for (i, j) in d.rz_nz]),

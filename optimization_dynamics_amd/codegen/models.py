@@ -65,6 +65,9 @@ class ModelSpec:
 
 
 def _syms(prefix, n):
+    # symbols are named as the C array elements they are printed as (z[3], th[7], ...)
+    if prefix in ("z", "th"):
+        return [sp.Symbol(f"{prefix}[{i}]", real=True) for i in range(n)]
     return [sp.Symbol(f"{prefix}{i}", real=True) for i in range(n)]
 
 

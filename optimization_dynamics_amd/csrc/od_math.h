@@ -28,6 +28,25 @@ OD_HD float od_sqrt(float x) { return sqrtf(x); }
 OD_HD float od_abs(float x) { return fabsf(x); }
 OD_HD float od_pow(float x, float y) { return powf(x, y); }
 
+// reciprocal: hardware seed + Newton refinement on the device (about 1 ulp, no denormal / inf
+// special-casing -- operands here are pivots, norms and step denominators), plain division on host
+#if defined(__HIP_DEVICE_COMPILE__)
+OD_HD double od_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+OD_HD float od_rcp(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+  return r;
+}
+#else
+OD_HD double od_rcp(double x) { return 1.0 / x; }
+OD_HD float od_rcp(float x) { return 1.0f / x; }
+#endif
+
 template <class T> OD_HD T od_min(T a, T b) { return a < b ? a : b; }
 template <class T> OD_HD T od_max(T a, T b) { return a > b ? a : b; }
 
@@ -43,7 +62,7 @@ template <int N, class T> OD_HD T od_powi(T x) {
 // Dense LU with partial pivoting for the small "tail" block left after the static elimination
 // (N = nq for the mechanical models).  Fully unrolled; row exchanges are done with selects so the
 // N*N block stays in registers (no dynamically indexed private array -> no scratch).
-// A is column-major N x N, overwritten by L\U of P*A.
+// A is column-major N x N, overwritten by L\U of P*A with the diagonal of U stored inverted.
 // ---------------------------------------------------------------------------------------------
 template <class T, int N> OD_HD bool od_lu_factor(T* A, int* piv) {
   bool ok = true;
@@ -68,7 +87,8 @@ template <class T, int N> OD_HD bool od_lu_factor(T* A, int* piv) {
         A[i + N * j] = sw ? u : w;
       }
     }
-    const T inv = T(1) / A[k + N * k];
+    const T inv = od_rcp(A[k + N * k]);
+    A[k + N * k] = inv;                       // the diagonal holds 1/u_kk
 #pragma unroll
     for (int i = k + 1; i < N; ++i) A[i + N * k] *= inv;
 #pragma unroll
@@ -100,7 +120,7 @@ template <class T, int N> OD_HD void od_lu_solve(const T* A, const int* piv, T* 
   }
 #pragma unroll
   for (int k = N - 1; k >= 0; --k) {
-    b[k] /= A[k + N * k];
+    b[k] *= A[k + N * k];
 #pragma unroll
     for (int i = 0; i < k; ++i) b[i] -= A[i + N * k] * b[k];
   }

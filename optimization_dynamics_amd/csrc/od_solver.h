@@ -56,14 +56,15 @@ template <int N, class T> OD_HD T soc_step_one(const T* lam, const T* dlt, T tau
   ll = od_max(ll, T(1e-25)) + eps;
   ld += eps;
   const T sq = od_sqrt(ll);
-  const T rs = ld / ll;
-  const T c = (ld / sq + dlt[0]) / (l0 / sq + T(1));
+  const T isq = od_rcp(sq), ill = isq * isq;
+  const T rs = ld * ill;
+  const T c = (ld * isq + dlt[0]) * od_rcp(l0 * isq + T(1));
   T nv = T(0);
 #pragma unroll
-  for (int i = 1; i < N; ++i) { const T rv = dlt[i] / sq - c * lam[i] / ll; nv += rv * rv; }
+  for (int i = 1; i < N; ++i) { const T rv = dlt[i] * isq - c * lam[i] * ill; nv += rv * rv; }
   nv = od_sqrt(nv);
   T a = T(1);
-  if (nv - rs > T(0)) a = od_min(a, tau / (nv - rs));
+  if (nv - rs > T(0)) a = od_min(a, tau * od_rcp(nv - rs));
   return a;
 }
 
@@ -84,12 +85,16 @@ template <class M, int C, class T> OD_HD T soc_step_cone(const T* z, const T* D,
 template <class M, class T> OD_HD T step_length(const T* z, const T* D, T tau_ort, T tau_soc) {
   T a = T(1);
   if constexpr (M::NORT > 0) {
+    // min over the ratio tests tau*z_k/D_k (D_k > 0) kept as a fraction: one reciprocal at the end
+    T num = T(1), den = T(1);
 #pragma unroll
     for (int i = 0; i < M::NORT; ++i) {
       const int k1 = M::ORT1[i], k2 = M::ORT2[i];
-      if (D[k1] > T(0)) a = od_min(a, tau_ort * z[k1] / D[k1]);
-      if (D[k2] > T(0)) a = od_min(a, tau_ort * z[k2] / D[k2]);
+      const T n1 = tau_ort * z[k1], n2 = tau_ort * z[k2];
+      if (D[k1] > T(0) && n1 * den < num * D[k1]) { num = n1; den = D[k1]; }
+      if (D[k2] > T(0) && n2 * den < num * D[k2]) { num = n2; den = D[k2]; }
     }
+    a = num * od_rcp(den);
   }
   if constexpr (M::NSOC > 0) a = soc_step_cone<M, 0>(z, D, tau_soc, a);
   return a;
@@ -115,8 +120,8 @@ template <class M, class T> OD_HD T centering_kappa(const T* z, const T* Da, T a
       sa += (z[a] - aaff * Da[a]) * (z[b] - aaff * Da[b]);
     }
   }
-  const T mu = s / T(n);
-  T q = (sa / T(n)) / mu;
+  const T mu = s * T(1.0 / n);
+  T q = sa * od_rcp(s);
   q = od_max(q, T(0));
   q = od_min(q, T(1));
   return q * q * q * mu;
@@ -136,7 +141,8 @@ template <class M, int C, class T> OD_HD void correction_cone(T* r, const T* Da)
 
 // rz evaluated with the orthant variables clamped from below at reg (regularisation of
 // rz!(ip, rz, z, theta; reg)), then factored.
-template <class M, class T> OD_HD bool eval_factor(const T* z, const T* th, T reg, typename M::template Fact<T>& f) {
+template <class M, class T>
+OD_HD bool eval_factor(const T* z, const T* th, const T* pre, const T* tr, T reg, typename M::template Fact<T>& f) {
   T zr[M::NZ];
 #pragma unroll
   for (int i = 0; i < M::NZ; ++i) zr[i] = z[i];
@@ -148,7 +154,7 @@ template <class M, class T> OD_HD bool eval_factor(const T* z, const T* th, T re
     }
   }
   T a[M::NNZ];
-  M::eval_rz(zr, th, a);
+  M::eval_rz(zr, th, pre, tr, a);
   return M::factor(a, f);
 }
 
@@ -159,8 +165,9 @@ template <class M, class T> OD_HD bool eval_factor(const T* z, const T* th, T re
 template <class M, class T, class Sink>
 OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, bool want_grad, Sink& sink, int* iters) {
   constexpr bool CONES = (M::NORT + M::NSOC) > 0;
-  T r[M::NZ], zs[M::NZ];
-  M::eval_r(z, th, r);
+  T r[M::NZ], zs[M::NZ], pre[M::NPRE], tr[M::NTR];
+  M::eval_pre(th, pre);
+  M::eval_r(z, th, pre, tr, r);
   T r_vio = viol_eq<M>(r), k_vio = viol_bil<M>(r);
   bool eval_done = !want_state, grad_done = !want_grad;
   int status = OD_ST_FACTOR_OK;
@@ -174,9 +181,9 @@ OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, boo
     if (!grad_done && ((req && k_vio < o.kappa_grad) || last)) {
       // differentiate_solution!: dz = -rz(z*)^{-1} rtheta(z*), reg = max(reg_val, kappa_tol*gamma_reg)
       const T reg = od_max(reg_prev, o.kappa_grad * o.gamma_reg);
-      if (!eval_factor<M>(z, th, reg, f)) status &= ~OD_ST_FACTOR_OK;
+      if (!eval_factor<M>(z, th, pre, tr, reg, f)) status &= ~OD_ST_FACTOR_OK;
       T g[M::NNZTH];
-      M::eval_rth(z, th, g);
+      M::eval_rth(z, th, pre, tr, g);
       for (int c = 0; c < M::NGC; ++c) {
         T b[M::NZ];
 #pragma unroll
@@ -202,7 +209,7 @@ OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, boo
 
     const T reg = (k_vio < o.kappa_reg) ? k_vio * o.gamma_reg : T(0);
     reg_prev = reg;
-    if (!eval_factor<M>(z, th, reg, f)) status &= ~OD_ST_FACTOR_OK;
+    if (!eval_factor<M>(z, th, pre, tr, reg, f)) status &= ~OD_ST_FACTOR_OK;
     T D[M::NZ];
     M::solve(f, r, D);                                   // affine (predictor) direction
     if constexpr (CONES) {
@@ -226,7 +233,7 @@ OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, boo
     for (int ls = 0; ls < o.max_ls; ++ls) {
 #pragma unroll
       for (int i = 0; i < M::NZ; ++i) zc[i] = z[i] - alpha * D[i];
-      M::eval_r(zc, th, r);
+      M::eval_r(zc, th, pre, tr, r);
       r_c = viol_eq<M>(r);
       k_c = viol_bil<M>(r);
       if (r_c <= r_vio || k_c <= k_vio) break;

@@ -30,7 +30,7 @@ class RocketInfo:
         o = self.lib.default_options("rocket_dynamics")      # dynamics.jl:21-27
         if dtype == torch.float32:
             # r_tol = 1e-8 is below fp32 resolution (eps ~ 6e-8 * |y|): rescaled, see DESIGN.md
-            o.r_tol = 2.0e-5
+            o.r_tol = 1.0e-4
         if options:
             for k, v in options.items():
                 setattr(o, k, v)
