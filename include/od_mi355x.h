@@ -79,6 +79,12 @@ int od_set_friction(od_handle h, const double* mu, int n);
 int od_set_u_max(od_handle h, double u_max);
 int od_set_layout(od_handle h, int layout);
 int od_set_stream(od_handle h, void* hip_stream);
+/* launch tuning.  ppw: problems per 64-lane wavefront (power of two <= 64, 0 = automatic) -- a wavefront
+ * is as slow as its slowest lane, so small batches are spread over more wavefronts.
+ * split_rollout: 1 = od_rollout runs the state recursion first (recording each knot's gradient iterate)
+ * and all T*B implicit gradients in a second, fully parallel launch; 0 = single fused launch;
+ * -1 = automatic.  Results are identical either way. */
+int od_set_launch_config(od_handle h, int ppw, int split_rollout);
 int od_synchronize(od_handle h);
 
 /* f (src/dynamics.jl:81-94) for B knots: d = [q2; q3].  x: 2nq, u: nu, d: 2nq per problem.

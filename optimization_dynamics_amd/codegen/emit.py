@@ -523,7 +523,7 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
     o.write("  template <class T> struct Fact { T v[NFACT > 0 ? NFACT : 1]; int piv[MTAIL > 0 ? MTAIL : 1]; bool sw[NSWAP > 0 ? NSWAP : 1]; };\n\n")
     o.write("  // statically ordered sparse elimination (%d pivots) + %dx%d runtime-pivoted dense tail\n"
             % (len(m.elim), el.m, el.m))
-    o.write("  template <class T> OD_HD static bool factor(const T* a, Fact<T>& f) {\n")
+    o.write("  template <class T, class F> OD_HD static bool factor(const T* a, F& f) {\n")
     for k, (i, j) in enumerate(d.rz_nz):
         o.write("    T a_%d_%d = a[%d];\n" % (i, j, k))
     fills = sorted(el.final_pattern - set(d.rz_nz))
@@ -536,21 +536,25 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
         o.write("    " + ln + "\n")
     for ln in el.fac_lines:
         o.write("    " + ln + "\n")
+    if el.m > 0:
+        o.write("    T tl_[MTAIL * MTAIL];\n")
     for ii, i in enumerate(el.tail_rows):
         for jj, j in enumerate(el.tail_cols):
             if (i, j) in el.final_pattern:
-                o.write("    f.v[%d] = a_%d_%d;\n" % (el.tail_base + ii + el.m * jj, i, j))
+                o.write("    tl_[%d] = a_%d_%d;\n" % (ii + el.m * jj, i, j))
             else:
-                o.write("    f.v[%d] = T(0);\n" % (el.tail_base + ii + el.m * jj))
+                o.write("    tl_[%d] = T(0);\n" % (ii + el.m * jj))
     if el.m > 0:
-        o.write("    return od_lu_factor<T, MTAIL>(&f.v[TAIL_BASE], f.piv);\n")
+        o.write("    const bool ok_ = od_lu_factor<T, MTAIL>(tl_, f.piv);\n")
+        o.write("#pragma unroll\n    for (int i = 0; i < MTAIL * MTAIL; ++i) f.v[TAIL_BASE + i] = tl_[i];\n")
+        o.write("    return ok_;\n")
     else:
         o.write("    return true;\n")
     o.write("  }\n\n")
 
     # ---- solve ----
     o.write("  // x = rz^{-1} b using the stored factors (b and x may alias)\n")
-    o.write("  template <class T> OD_HD static void solve(const Fact<T>& f, const T* b, T* x) {\n")
+    o.write("  template <class T, class F> OD_HD static void solve(const F& f, const T* b, T* x) {\n")
     for i in range(m.nz):
         o.write("    T y_%d = b[%d];\n" % (i, i))
     for k, ((ra, rb), (ca, cb)) in enumerate(el.swaps):
@@ -562,7 +566,8 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
         o.write("    T t_[MTAIL];\n")
         for ii, i in enumerate(el.tail_rows):
             o.write("    t_[%d] = y_%d;\n" % (ii, i))
-        o.write("    od_lu_solve<T, MTAIL>(&f.v[TAIL_BASE], f.piv, t_);\n")
+        o.write("    T tl_[MTAIL * MTAIL];\n#pragma unroll\n    for (int i = 0; i < MTAIL * MTAIL; ++i) tl_[i] = f.v[TAIL_BASE + i];\n")
+        o.write("    od_lu_solve<T, MTAIL>(tl_, f.piv, t_);\n")
         for jj, j in enumerate(el.tail_cols):
             o.write("    const T x_%d = t_[%d];\n" % (j, jj))
     for (prw, pc, ip, us) in reversed(el.bwd):

@@ -118,6 +118,10 @@ struct od_handle_s {
   od_options opts;
   double h, fric[4], u_max;
   hipStream_t stream;
+  int ppw;         // problems per wavefront; 0 = automatic (od_auto_ppw)
+  int split;       // rollouts: -1 automatic, 0 fused single pass, 1 split (state pass + gradient pass)
+  double* work;    // device workspace of the split rollout
+  size_t work_elems;
   double* stage;   // device staging for the host scalar path
   size_t stage_elems;
 };
@@ -137,6 +141,26 @@ template <class T> View<const T> mkcview(const void* p, long E, long K, int layo
   if (layout == OD_LAYOUT_BATCH_MINOR) { v.se = K; v.sb = 1; }
   else { v.se = 1; v.sb = E; }
   return v;
+}
+
+int ppw_of(const od_handle_s* h, long n) { return h->ppw > 0 ? h->ppw : od_auto_ppw(n); }
+
+LaunchCfg cfg_of(const od_handle_s* h, long n) {
+  LaunchCfg c;
+  c.ppw = ppw_of(h, n);
+  c.wpb = 1;
+  c.lds = 0;
+  return c;
+}
+
+// split rollout, state pass: 4 wavefronts per workgroup (one per SIMD of a CU)
+LaunchCfg cfg_state(const od_handle_s* h, long n) {
+  LaunchCfg c;
+  c.wpb = 4;
+  c.lds = 0;
+  if (h->ppw > 0) c.ppw = h->ppw;
+  else c.ppw = od_auto_ppw(n);
+  return c;
 }
 
 // with cones and a finite undercut the centering floor depends on kappa_tol, so the two
@@ -186,14 +210,14 @@ int run_step(od_handle_s* h, const char* fn, long B, const void* x, const void* 
     // two passes, exactly like the reference's eval_sim / grad_sim pair
     StepArgs<double> e = a;
     e.want_grad = 0; e.dx.p = nullptr; e.du.p = nullptr; e.dq3.p = nullptr;
-    OD_HIP(h->vt->step(e, h->stream));
+    OD_HIP(h->vt->step(e, cfg_of(h, B), h->stream));
     StepArgs<double> g = a;
     g.d.p = nullptr; g.opts.kappa_eval = g.opts.kappa_grad;
     g.status.p = nullptr; g.iters.p = nullptr;
-    OD_HIP(h->vt->step(g, h->stream));
+    OD_HIP(h->vt->step(g, cfg_of(h, B), h->stream));
     return OD_OK;
   }
-  OD_HIP(h->vt->step(a, h->stream));
+  OD_HIP(h->vt->step(a, cfg_of(h, B), h->stream));
   return OD_OK;
 }
 
@@ -223,8 +247,8 @@ template <class T> static int rocket_impl(od_handle h, long B, int project, cons
   a.uproj = mkview<T>(uproj, 3, B, L);
   a.status = mkview<int>(status, 1, B, L);
   hipError_t e;
-  if constexpr (sizeof(T) == 8) e = launch_rocket64(a, h->stream);
-  else e = launch_rocket32(a, h->stream);
+  if constexpr (sizeof(T) == 8) e = launch_rocket64(a, ppw_of(h, B), h->stream);
+  else e = launch_rocket32(a, ppw_of(h, B), h->stream);
   if (e != hipSuccess) return fail(OD_ERR_HIP, std::string("od_rocket launch: ") + hipGetErrorString(e));
   return OD_OK;
 }
@@ -284,6 +308,10 @@ int od_create(int model, int dtype, const od_options* opts, double dt, od_handle
   for (int i = 0; i < 4; ++i) h->fric[i] = vt->fric_default[i];
   h->u_max = 12.5;   // examples/rocket.jl:16
   h->stream = nullptr;
+  h->ppw = 0;
+  h->split = -1;
+  h->work = nullptr;
+  h->work_elems = 0;
   h->stage = nullptr;
   h->stage_elems = 0;
   *out = h;
@@ -293,6 +321,7 @@ int od_create(int model, int dtype, const od_options* opts, double dt, od_handle
 int od_destroy(od_handle h) {
   if (!h) return OD_OK;
   if (h->stage) (void)hipFree(h->stage);
+  if (h->work) (void)hipFree(h->work);
   delete h;
   return OD_OK;
 }
@@ -332,6 +361,13 @@ int od_set_stream(od_handle h, void* s) {
   h->stream = (hipStream_t)s;
   return OD_OK;
 }
+int od_set_launch_config(od_handle h, int ppw, int split_rollout) {
+  if (!h || ppw < 0 || ppw > 64 || (ppw & (ppw - 1)) || split_rollout < -1 || split_rollout > 1)
+    return fail(OD_ERR_INVALID, "od_set_launch_config: ppw = 0 (auto) or a power of two <= 64; split_rollout in {-1, 0, 1}");
+  h->ppw = ppw;
+  h->split = split_rollout;
+  return OD_OK;
+}
 int od_synchronize(od_handle h) {
   if (!h) return fail(OD_ERR_INVALID, "od_synchronize: null handle");
   OD_HIP(hipStreamSynchronize(h->stream));
@@ -359,7 +395,7 @@ int od_step_grad_compact(od_handle h, long B, const void* x, const void* u, void
     a.d_skip_q2 = 1;
   }
   if (a.want_grad && !fusable(h)) return fail(OD_ERR_UNSUPPORTED, "od_step_grad_compact: finite undercut with kappa_eval != kappa_grad; use od_step + od_step_grad");
-  OD_HIP(h->vt->step(a, h->stream));
+  OD_HIP(h->vt->step(a, cfg_of(h, B), h->stream));
   return OD_OK;
 }
 
@@ -368,17 +404,46 @@ int od_rollout(od_handle h, long B, int T, const void* x1, const void* U, void* 
   if (B <= 0 || T <= 0) return OD_OK;
   if (!x1 || !U || !X) return fail(OD_ERR_INVALID, "od_rollout: null x1/U/X");
   if (!fusable(h) && (A || Bm)) return fail(OD_ERR_UNSUPPORTED, "od_rollout: finite undercut with kappa_eval != kappa_grad");
-  const int n = 2 * h->vt->nq;
+  const int n = 2 * h->vt->nq, nz = h->vt->nz;
   const long K = (long)T * B;
+  const int want_grad = (A || Bm) ? 1 : 0;
   RolloutArgs<double> r;
-  r.s = step_args(h, B, K, x1, U, nullptr, A, Bm, nullptr, status, iters, (A || Bm) ? 1 : 0);
+  r.s = step_args(h, B, K, x1, U, nullptr, A, Bm, nullptr, status, iters, want_grad);
   // X has (T+1)*B slots; knot k's d goes to slot k + B
   View<double> xv = mkview<double>(X, n, (long)(T + 1) * B, h->layout);
   r.x0 = xv;
-  xv.p += (long)B * xv.sb;
-  r.s.d = xv;
+  View<double> dv = xv;
+  dv.p += (long)B * dv.sb;
+  r.s.d = dv;
   r.Tn = T;
-  OD_HIP(h->vt->rollout(r, h->stream));
+  const bool split = want_grad && (h->split >= 0 ? h->split != 0 : true);
+  if (!split) {
+    OD_HIP(h->vt->rollout(r, cfg_of(h, B), h->stream));
+    return OD_OK;
+  }
+  // pass 1: state recursion (records the gradient iterate of every knot); pass 2: all gradients
+  const size_t need = (size_t)(nz + 1) * (size_t)K;
+  if (h->work_elems < need) {
+    if (h->work) { OD_HIP(hipStreamSynchronize(h->stream)); (void)hipFree(h->work); h->work = nullptr; h->work_elems = 0; }
+    OD_HIP(hipMalloc((void**)&h->work, need * sizeof(double)));
+    h->work_elems = need;
+  }
+  RolloutStateArgs<double> rs;
+  rs.r = r;
+  rs.r.s.dx.p = nullptr; rs.r.s.du.p = nullptr; rs.r.s.dq3.p = nullptr;
+  rs.zg = mkview<double>(h->work, nz + 1, K, OD_LAYOUT_BATCH_MINOR);
+  OD_HIP(h->vt->rollout_state(rs, cfg_state(h, B), h->stream));
+  GradKnotArgs<double> g;
+  g.s = r.s;
+  g.s.B = K;
+  View<const double> xin;
+  xin.p = xv.p; xin.se = xv.se; xin.sb = xv.sb;     // state of knot k = slot k of X
+  g.s.x = xin;
+  g.s.d.p = nullptr;
+  g.s.iters.p = nullptr;
+  g.zg.p = h->work; g.zg.se = K; g.zg.sb = 1;
+  g.K = K;
+  OD_HIP(h->vt->grad_knots(g, h->stream));
   return OD_OK;
 }
 
@@ -401,10 +466,10 @@ int od_bundle_grad(od_handle h, long B, int N, const void* x, const void* u, con
   a.eta = (const double*)eta;
   a.feta = mkview<double>(ws, nq, P, OD_LAYOUT_BATCH_MINOR);
   a.status = mkview<int>((char*)ws + sizeof(double) * (size_t)nq * P, 1, P, OD_LAYOUT_BATCH_MINOR);
-  OD_HIP(h->vt->bundle(a, P, h->stream));
+  OD_HIP(h->vt->bundle(a, P, ppw_of(h, P), h->stream));
   View<const double> fv;
   fv.p = a.feta.p; fv.se = a.feta.se; fv.sb = a.feta.sb;
-  hipLaunchKernelGGL(k_lsfit, od_grid(B), dim3(OD_BLOCK), 0, h->stream, B, N, nq, nzb, (const double*)eta, fv,
+  hipLaunchKernelGGL(k_lsfit, od_grid(B, OD_BLOCK), dim3(OD_BLOCK), 0, h->stream, B, N, nq, nzb, (const double*)eta, fv,
                      mkview<double>(dz, nq * nzb, B, h->layout), mkview<int>(status, 1, B, h->layout));
   OD_HIP(hipGetLastError());
   return OD_OK;
@@ -416,7 +481,7 @@ int od_ls_fit(od_handle h, long B, int N, int ny, int nzb, const void* eta, cons
   if (N <= 0 || ny <= 0 || nzb <= 0 || ny > OD_LS_MAX || nzb > OD_LS_MAX || !eta || !feta || !M)
     return fail(OD_ERR_INVALID, "od_ls_fit: bad arguments (ny, nzb <= 24)");
   View<const double> fv = mkcview<double>(feta, ny, (long)(N + 1) * B, OD_LAYOUT_BATCH_MINOR);
-  hipLaunchKernelGGL(k_lsfit, od_grid(B), dim3(OD_BLOCK), 0, h->stream, B, N, ny, nzb, (const double*)eta, fv,
+  hipLaunchKernelGGL(k_lsfit, od_grid(B, OD_BLOCK), dim3(OD_BLOCK), 0, h->stream, B, N, ny, nzb, (const double*)eta, fv,
                      mkview<double>(M, ny * nzb, B, h->layout), mkview<int>(status, 1, B, h->layout));
   OD_HIP(hipGetLastError());
   return OD_OK;
@@ -440,7 +505,7 @@ int od_ip_solve(od_handle h, long B, const void* z0, const void* theta, void* z,
     a.status = mkview<int>(status, 1, B, L);
     a.iters = mkview<int>(iters, 2, B, L);
     a.want_grad = dz ? 1 : 0;
-    OD_HIP(vt->raw64(a, h->stream));
+    OD_HIP(vt->raw64(a, ppw_of(h, B), h->stream));
   } else {
     RawArgs<float> a;
     a.B = B;
@@ -453,7 +518,7 @@ int od_ip_solve(od_handle h, long B, const void* z0, const void* theta, void* z,
     a.status = mkview<int>(status, 1, B, L);
     a.iters = mkview<int>(iters, 2, B, L);
     a.want_grad = dz ? 1 : 0;
-    OD_HIP(vt->raw32(a, h->stream));
+    OD_HIP(vt->raw32(a, ppw_of(h, B), h->stream));
   }
   return OD_OK;
 }

@@ -30,11 +30,12 @@ OD_HD float od_pow(float x, float y) { return powf(x, y); }
 
 // reciprocal: hardware seed + Newton refinement on the device (about 1 ulp, no denormal / inf
 // special-casing -- operands here are pivots, norms and step denominators), plain division on host
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OD_EXACT_RCP)
 OD_HD double od_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
   r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
   r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);   // two steps measurably stall ill-conditioned solves on gfx950
   return r;
 }
 OD_HD float od_rcp(float x) {
@@ -42,6 +43,14 @@ OD_HD float od_rcp(float x) {
   r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
   return r;
 }
+#elif defined(OD_EMULATE_RCP)   // test harness: mimic the device sequence (24-bit seed + 2 Newton steps)
+OD_HD double od_rcp(double x) {
+  double r = (double)(float)(1.0 / x);
+  r = std::fma(std::fma(-x, r, 1.0), r, r);
+  r = std::fma(std::fma(-x, r, 1.0), r, r);
+  return r;
+}
+OD_HD float od_rcp(float x) { return 1.0f / x; }
 #else
 OD_HD double od_rcp(double x) { return 1.0 / x; }
 OD_HD float od_rcp(float x) { return 1.0f / x; }

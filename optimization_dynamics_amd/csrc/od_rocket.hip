@@ -7,17 +7,17 @@
 
 namespace od {
 
-template <class T> __global__ __launch_bounds__(OD_BLOCK) void k_rocket(RocketArgs<T> a) {
-  const long b = (long)blockIdx.x * OD_BLOCK + threadIdx.x;
-  if (b < a.B) unit_rocket<Model_rocket_dynamics, Model_rocket_projection, T>(a, b);
+template <class T> __global__ __launch_bounds__(OD_BLOCK) void k_rocket(RocketArgs<T> a, LaneMap lm) {
+  const long b = lm.problem(blockIdx.x, threadIdx.x);
+  if (lm.active(threadIdx.x) && b < a.B) unit_rocket<Model_rocket_dynamics, Model_rocket_projection, T>(a, b);
 }
 
-hipError_t launch_rocket64(const RocketArgs<double>& a, hipStream_t s) {
-  hipLaunchKernelGGL((k_rocket<double>), od_grid(a.B), dim3(OD_BLOCK), 0, s, a);
+hipError_t launch_rocket64(const RocketArgs<double>& a, int ppw, hipStream_t s) {
+  hipLaunchKernelGGL((k_rocket<double>), od_grid(a.B, ppw), dim3(OD_BLOCK), 0, s, a, LaneMap{ppw, 0});
   return hipGetLastError();
 }
-hipError_t launch_rocket32(const RocketArgs<float>& a, hipStream_t s) {
-  hipLaunchKernelGGL((k_rocket<float>), od_grid(a.B), dim3(OD_BLOCK), 0, s, a);
+hipError_t launch_rocket32(const RocketArgs<float>& a, int ppw, hipStream_t s) {
+  hipLaunchKernelGGL((k_rocket<float>), od_grid(a.B, ppw), dim3(OD_BLOCK), 0, s, a, LaneMap{ppw, 0});
   return hipGetLastError();
 }
 

@@ -141,8 +141,8 @@ template <class M, int C, class T> OD_HD void correction_cone(T* r, const T* Da)
 
 // rz evaluated with the orthant variables clamped from below at reg (regularisation of
 // rz!(ip, rz, z, theta; reg)), then factored.
-template <class M, class T>
-OD_HD bool eval_factor(const T* z, const T* th, const T* pre, const T* tr, T reg, typename M::template Fact<T>& f) {
+template <class M, class T, class F>
+OD_HD bool eval_factor(const T* z, const T* th, const T* pre, const T* tr, T reg, F& f) {
   T zr[M::NZ];
 #pragma unroll
   for (int i = 0; i < M::NZ; ++i) zr[i] = z[i];
@@ -162,8 +162,21 @@ OD_HD bool eval_factor(const T* z, const T* th, const T* pre, const T* tr, T reg
 //
 // z: in = initial guess, out = iterate at (r_tol, kappa_eval) convergence (or the last iterate).
 // Returns status bits; iters[0] = iterations to kappa_eval, iters[1] = iterations to kappa_grad.
-template <class M, class T, class Sink>
-OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, bool want_grad, Sink& sink, int* iters) {
+// Factor storage in LDS: element k of this lane lives at p[k * stride] (stride = lane slots of the
+// workgroup), i.e. consecutive lanes hit consecutive 8-byte words -> conflict-free ds_read/write_b64.
+template <class T> struct StridedVec {
+  T* p;
+  int stride;
+  OD_HD T& operator[](int k) const { return p[(long)k * stride]; }
+};
+template <class M, class T> struct LdsFact {
+  StridedVec<T> v;
+  int piv[M::MTAIL > 0 ? M::MTAIL : 1];
+  bool sw[M::NSWAP > 0 ? M::NSWAP : 1];
+};
+
+template <class M, class T, class Sink, class F>
+OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, bool want_grad, Sink& sink, int* iters, F& f) {
   constexpr bool CONES = (M::NORT + M::NSOC) > 0;
   T r[M::NZ], zs[M::NZ], pre[M::NPRE], tr[M::NTR];
   M::eval_pre(th, pre);
@@ -173,7 +186,6 @@ OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, boo
   int status = OD_ST_FACTOR_OK;
   T reg_prev = T(0);
   iters[0] = iters[1] = 0;
-  typename M::template Fact<T> f;
   int it = 0;
   for (;; ++it) {
     const bool req = r_vio < o.r_tol;
@@ -181,6 +193,11 @@ OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, boo
     if (!grad_done && ((req && k_vio < o.kappa_grad) || last)) {
       // differentiate_solution!: dz = -rz(z*)^{-1} rtheta(z*), reg = max(reg_val, kappa_tol*gamma_reg)
       const T reg = od_max(reg_prev, o.kappa_grad * o.gamma_reg);
+      if constexpr (Sink::DEFER_GRAD) {
+        // the gradient is computed later by a separate, fully parallel pass (gradient_at): only
+        // record where -- keeps rtheta / the right-hand sides out of this loop's register budget
+        sink.defer(z, reg);
+      } else {
       if (!eval_factor<M>(z, th, pre, tr, reg, f)) status &= ~OD_ST_FACTOR_OK;
       T g[M::NNZTH];
       M::eval_rth(z, th, pre, tr, g);
@@ -193,6 +210,7 @@ OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, boo
         M::solve(f, b, b);
 #pragma unroll
         for (int i = 0; i < M::NZQ; ++i) sink.grad(i, c, -b[M::ZQ[i]]);
+      }
       }
       grad_done = true;
       iters[1] = it;
@@ -250,6 +268,36 @@ OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, boo
     for (int i = 0; i < M::NZ; ++i) z[i] = zs[i];
   }
   return status;
+}
+
+// Implicit gradient at a recorded iterate (second pass of the split rollout): dz = -rz(z)^{-1} rtheta(z)
+// with the orthant clamp `reg` that differentiate_solution! used.  Returns false if a pivot vanished.
+template <class M, class T, class Sink> OD_HD bool gradient_at(const T* th, const T* z, T reg, Sink& sink) {
+  T pre[M::NPRE], tr[M::NTR], r[M::NZ];
+  M::eval_pre(th, pre);
+  M::eval_r(z, th, pre, tr, r);          // produces the shared trigonometric values at z
+  typename M::template Fact<T> f;
+  const bool ok = eval_factor<M>(z, th, pre, tr, reg, f);
+  T g[M::NNZTH];
+  M::eval_rth(z, th, pre, tr, g);
+  for (int c = 0; c < M::NGC; ++c) {
+    T b[M::NZ];
+#pragma unroll
+    for (int i = 0; i < M::NZ; ++i) b[i] = T(0);
+#pragma unroll
+    for (int k = 0; k < M::NNZTH; ++k) b[M::RTH_ROW[k]] = (M::RTH_COL[k] == c) ? g[k] : b[M::RTH_ROW[k]];
+    M::solve(f, b, b);
+#pragma unroll
+    for (int i = 0; i < M::NZQ; ++i) sink.grad(i, c, -b[M::ZQ[i]]);
+  }
+  return ok;
+}
+
+// convenience: factor storage in registers
+template <class M, class T, class Sink>
+OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, bool want_grad, Sink& sink, int* iters) {
+  typename M::template Fact<T> f;
+  return ip_step_grad<M, T, Sink>(o, th, z, want_state, want_grad, sink, iters, f);
 }
 
 // theta = [q2 - h*v1 ; q2 ; u ; friction ; h] and z0 = initialize_z!(q2) for the mechanical models

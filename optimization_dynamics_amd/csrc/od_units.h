@@ -35,8 +35,10 @@ template <class T> struct StepArgs {
 };
 
 template <class M, class T> struct StepSink {
+  static constexpr bool DEFER_GRAD = false;
   const StepArgs<T>& a;
   long b;
+  OD_HD void defer(const T*, T) {}
   OD_HD void grad(int i, int c, T v) {
     constexpr int nq = M::NQ, n = 2 * M::NQ;
     if (a.dq3.ok()) a.dq3.at(i + nq * c, b) = v;
@@ -46,14 +48,14 @@ template <class M, class T> struct StepSink {
 };
 
 // one knot: x=[q1;q2], u -> d=[q2;q3], dx, du.  Returns status.
-template <class M, class T>
-OD_HD int unit_step_core(const StepArgs<T>& a, long b, const T* xin, const T* uin, T* q3out) {
+template <class M, class T, class F>
+OD_HD int unit_step_core(const StepArgs<T>& a, long b, const T* xin, const T* uin, T* q3out, F& f) {
   constexpr int nq = M::NQ, n = 2 * M::NQ;
   T th[M::NTH], z[M::NZ];
   mech_setup<M>(xin, xin + nq, uin, a.fric, a.h, th, z);
   StepSink<M, T> sink{a, b};
   int it[2];
-  const int st = ip_step_grad<M>(a.opts, th, z, true, a.want_grad != 0, sink, it);
+  const int st = ip_step_grad<M, T>(a.opts, th, z, true, a.want_grad != 0, sink, it, f);
 #pragma unroll
   for (int i = 0; i < nq; ++i) q3out[i] = z[M::ZQ[i]];
   if (a.d.ok()) {
@@ -84,14 +86,18 @@ OD_HD int unit_step_core(const StepArgs<T>& a, long b, const T* xin, const T* ui
   return st;
 }
 
-template <class M, class T> OD_HD void unit_step_grad(const StepArgs<T>& a, long b) {
+template <class M, class T, class F> OD_HD void unit_step_grad(const StepArgs<T>& a, long b, F& f) {
   constexpr int nq = M::NQ, n = 2 * M::NQ;
   T x[n], u[M::NU > 0 ? M::NU : 1], q3[nq];
 #pragma unroll
   for (int i = 0; i < n; ++i) x[i] = a.x.at(i, b);
 #pragma unroll
   for (int i = 0; i < M::NU; ++i) u[i] = a.u.at(i, b);
-  unit_step_core<M, T>(a, b, x, u, q3);
+  unit_step_core<M, T>(a, b, x, u, q3, f);
+}
+template <class M, class T> OD_HD void unit_step_grad(const StepArgs<T>& a, long b) {
+  typename M::template Fact<T> f;
+  unit_step_grad<M, T>(a, b, f);
 }
 
 // ---- rollout: T sequential steps per trajectory, state carried in registers ------------------
@@ -102,7 +108,7 @@ template <class T> struct RolloutArgs {
   int Tn;
 };
 
-template <class M, class T> OD_HD void unit_rollout(const RolloutArgs<T>& ra, long b) {
+template <class M, class T, class F> OD_HD void unit_rollout(const RolloutArgs<T>& ra, long b, F& f) {
   constexpr int nq = M::NQ, n = 2 * M::NQ;
   const StepArgs<T>& a = ra.s;
   T x[n], u[M::NU > 0 ? M::NU : 1], q3[nq];
@@ -116,11 +122,112 @@ template <class M, class T> OD_HD void unit_rollout(const RolloutArgs<T>& ra, lo
     const long k = (long)t * a.B + b;
 #pragma unroll
     for (int i = 0; i < M::NU; ++i) u[i] = a.u.at(i, k);
-    unit_step_core<M, T>(a, k, x, u, q3);
+    unit_step_core<M, T>(a, k, x, u, q3, f);
 #pragma unroll
     for (int i = 0; i < nq; ++i) { x[i] = x[nq + i]; x[nq + i] = q3[i]; }
   }
 }
+template <class M, class T> OD_HD void unit_rollout(const RolloutArgs<T>& ra, long b) {
+  typename M::template Fact<T> f;
+  unit_rollout<M, T>(ra, b, f);
+}
+
+// ---- split rollout: (1) state recursion recording the gradient iterate, (2) gradients per knot -----
+// The time recursion only needs q3; the implicit gradient of knot t does not feed knot t+1.  Pass 1
+// keeps the critical path short (no rtheta / gradient right-hand sides in its register budget) and
+// stores, per knot, the iterate z_g at which the reference's grad simulator would have stopped and
+// the clamp it would have used.  Pass 2 is embarrassingly parallel over all T*B knots.
+template <class T> struct RolloutStateArgs {
+  RolloutArgs<T> r;     // r.s.dx / du / dq3 unused here
+  View<T> zg;           // NZ + 1 per knot: z at the gradient iterate, then the clamp reg
+};
+
+template <class M, class T> struct DeferSink {
+  static constexpr bool DEFER_GRAD = true;
+  const View<T>& zg;
+  long k;
+  OD_HD void grad(int, int, T) {}
+  OD_HD void defer(const T* z, T reg) {
+#pragma unroll
+    for (int i = 0; i < M::NZ; ++i) zg.at(i, k) = z[i];
+    zg.at(M::NZ, k) = reg;
+  }
+};
+
+template <class M, class T> OD_HD void unit_rollout_state(const RolloutStateArgs<T>& ra, long b) {
+  constexpr int nq = M::NQ, n = 2 * M::NQ;
+  const StepArgs<T>& a = ra.r.s;
+  T x[n], u[M::NU > 0 ? M::NU : 1];
+#pragma unroll
+  for (int i = 0; i < n; ++i) x[i] = a.x.at(i, b);
+  if (ra.r.x0.ok()) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) ra.r.x0.at(i, b) = x[i];
+  }
+  for (int t = 0; t < ra.r.Tn; ++t) {
+    const long k = (long)t * a.B + b;
+#pragma unroll
+    for (int i = 0; i < M::NU; ++i) u[i] = a.u.at(i, k);
+    T th[M::NTH], z[M::NZ];
+    mech_setup<M>(x, x + nq, u, a.fric, a.h, th, z);
+    DeferSink<M, T> sink{ra.zg, k};
+    int it[2];
+    const int st = ip_step_grad<M>(a.opts, th, z, true, a.want_grad != 0, sink, it);
+#pragma unroll
+    for (int i = 0; i < nq; ++i) { x[i] = x[nq + i]; x[nq + i] = z[M::ZQ[i]]; }
+    if (a.d.ok()) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) a.d.at(i, k) = x[i];
+    }
+    if (a.status.ok()) a.status.at(0, k) = st;
+    if (a.iters.ok()) { a.iters.at(0, k) = it[0]; a.iters.at(1, k) = it[1]; }
+  }
+}
+
+// pass 2: knot k = t*B + b reads its state from X (slot k) and its control, rebuilds theta, and
+// differentiates at the recorded iterate
+template <class T> struct GradKnotArgs {
+  StepArgs<T> s;        // x = X view over (T+1)*B slots, u per knot, dx/du/dq3 outputs per knot, status per knot
+  View<const T> zg;
+  long K;               // number of knots
+};
+
+template <class M, class T> OD_HD void unit_grad_knot(const GradKnotArgs<T>& ga, long k) {
+  constexpr int nq = M::NQ, n = 2 * M::NQ;
+  const StepArgs<T>& a = ga.s;
+  T x[n], u[M::NU > 0 ? M::NU : 1], th[M::NTH], z[M::NZ];
+#pragma unroll
+  for (int i = 0; i < n; ++i) x[i] = a.x.at(i, k);
+#pragma unroll
+  for (int i = 0; i < M::NU; ++i) u[i] = a.u.at(i, k);
+  mech_setup<M>(x, x + nq, u, a.fric, a.h, th, z);
+#pragma unroll
+  for (int i = 0; i < M::NZ; ++i) z[i] = ga.zg.at(i, k);
+  const T reg = ga.zg.at(M::NZ, k);
+  StepSink<M, T> sink{a, k};
+  const bool ok = gradient_at<M>(th, z, reg, sink);
+  if (a.dx.ok()) {
+#pragma unroll
+    for (int c = 0; c < n; ++c) {
+#pragma unroll
+      for (int i = 0; i < nq; ++i) a.dx.at(i + n * c, k) = (c == nq + i) ? T(1) : T(0);
+    }
+  }
+  if (a.du.ok()) {
+#pragma unroll
+    for (int c = 0; c < M::NU; ++c) {
+#pragma unroll
+      for (int i = 0; i < nq; ++i) a.du.at(i + n * c, k) = T(0);
+    }
+  }
+  if (!ok && a.status.ok()) a.status.at(0, k) = a.status.at(0, k) & ~OD_ST_FACTOR_OK;
+}
+
+template <class T> struct NoGradSink {
+  static constexpr bool DEFER_GRAD = false;
+  OD_HD void grad(int, int, T) {}
+  OD_HD void defer(const T*, T) {}
+};
 
 // ---- gradient bundle samples (src/gradient_bundle.jl:87-100) ---------------------------------
 // problem p = b*(N+1) + i : i = 0 nominal, i >= 1 perturbed by eta[:, i-1]; EVAL simulator, no grad.
@@ -144,7 +251,7 @@ template <class M, class T> OD_HD void unit_bundle_sample(const BundleArgs<T>& b
   for (int k = 0; k < M::NU; ++k) u[k] = a.u.at(k, b) + (i > 0 ? ba.eta[n + k + nzb * (i - 1)] : T(0));
   T th[M::NTH], z[M::NZ];
   mech_setup<M>(x, x + nq, u, a.fric, a.h, th, z);
-  struct NoSink { OD_HD void grad(int, int, T) {} } sink;
+  NoGradSink<T> sink;
   int it[2];
   const int st = ip_step_grad<M>(a.opts, th, z, true, false, sink, it);
 #pragma unroll
@@ -166,8 +273,10 @@ template <class T> struct RawArgs {
 };
 
 template <class M, class T> struct RawSink {
+  static constexpr bool DEFER_GRAD = false;
   const RawArgs<T>& a;
   long b;
+  OD_HD void defer(const T*, T) {}
   OD_HD void grad(int i, int c, T v) { if (a.dz.ok()) a.dz.at(i + M::NZQ * c, b) = v; }
 };
 
@@ -202,6 +311,32 @@ template <class T> struct RocketArgs {
   View<int> status;   // bit0/1 dyn eval/grad ok, bit4/5 projection eval/grad ok
 };
 
+// d(projected u)/du: 3 x 3 col-major kept in registers (column index is dynamic -> selects)
+template <class T> struct ProjSink {
+  static constexpr bool DEFER_GRAD = false;
+  T* d;
+  OD_HD void defer(const T*, T) {}
+  OD_HD void grad(int i, int c, T v) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d[i + 3 * k] = (c == k) ? v : d[i + 3 * k];
+  }
+};
+// dz_dyn: x-columns go straight to dx, the three u-columns are collected for the chain product
+template <class T> struct RocketDynSink {
+  static constexpr bool DEFER_GRAD = false;
+  const RocketArgs<T>& a;
+  long b;
+  T* dyn_u;
+  OD_HD void defer(const T*, T) {}
+  OD_HD void grad(int i, int c, T v) {
+    if (c < 12) { if (a.dx.ok()) a.dx.at(i + 12 * c, b) = v; }
+    else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dyn_u[i + 12 * k] = (c - 12 == k) ? v : dyn_u[i + 12 * k];
+    }
+  }
+};
+
 template <class MD, class MP, class T> OD_HD void unit_rocket(const RocketArgs<T>& a, long b) {
   T x[12], u[3];
 #pragma unroll
@@ -216,13 +351,7 @@ template <class MD, class MP, class T> OD_HD void unit_rocket(const RocketArgs<T
 #pragma unroll
     for (int i = 0; i < MP::NZ; ++i) zp[i] = T(MP::ZI_VAL[i]);
     thp[0] = u[0]; thp[1] = u[1]; thp[2] = u[2]; thp[3] = a.u_max;
-    struct PSink {
-      T* d;
-      OD_HD void grad(int i, int c, T v) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) d[i + 3 * k] = (c == k) ? v : d[i + 3 * k];
-      }
-    } ps{dproj};
+    ProjSink<T> ps{dproj};
 #pragma unroll
     for (int i = 0; i < 9; ++i) dproj[i] = T(0);
     int itp[2];
@@ -238,17 +367,7 @@ template <class MD, class MP, class T> OD_HD void unit_rocket(const RocketArgs<T
   th[12] = u[0]; th[13] = u[1]; th[14] = u[2]; th[15] = a.h;
   // du with projection needs the 12x3 block times dproj: collect the u-columns in registers
   T dyn_u[36];
-  struct DSink2 {
-    const RocketArgs<T>& a; long b; T* dyn_u;
-    OD_HD void grad(int i, int c, T v) {
-      if (c < 12) { if (a.dx.ok()) a.dx.at(i + 12 * c, b) = v; }
-      else {
-        // c - 12 in {0,1,2}; static unroll keeps dyn_u in registers
-#pragma unroll
-        for (int k = 0; k < 3; ++k) dyn_u[i + 12 * k] = (c - 12 == k) ? v : dyn_u[i + 12 * k];
-      }
-    }
-  } ds{a, b, dyn_u};
+  RocketDynSink<T> ds{a, b, dyn_u};
 #pragma unroll
   for (int i = 0; i < 36; ++i) dyn_u[i] = T(0);
   int it[2];

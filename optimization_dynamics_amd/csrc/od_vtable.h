@@ -6,18 +6,22 @@
 
 namespace od {
 
+struct LaunchCfg { int ppw, wpb, lds; };     // problems per wavefront, wavefronts per block (1|4), LDS factors
+
 struct ModelVT {
   int id, kind;
   const char* name;
-  int nq, nu, nz, nth, nfric, nzq, ngc;
+  int nq, nu, nz, nth, nfric, nzq, ngc, nfact;
   double r_tol, kappa_eval, kappa_grad, eps_min, kappa_reg, gamma_reg, undercut;
   int max_iter, max_ls;
   double fric_default[4];
-  hipError_t (*step)(const StepArgs<double>&, hipStream_t);          // mech models
-  hipError_t (*rollout)(const RolloutArgs<double>&, hipStream_t);    // mech models
-  hipError_t (*bundle)(const BundleArgs<double>&, long, hipStream_t);
-  hipError_t (*raw64)(const RawArgs<double>&, hipStream_t);
-  hipError_t (*raw32)(const RawArgs<float>&, hipStream_t);
+  hipError_t (*step)(const StepArgs<double>&, LaunchCfg, hipStream_t);          // mech models
+  hipError_t (*rollout)(const RolloutArgs<double>&, LaunchCfg, hipStream_t);    // fused single-pass rollout
+  hipError_t (*rollout_state)(const RolloutStateArgs<double>&, LaunchCfg, hipStream_t);   // split rollout, pass 1
+  hipError_t (*grad_knots)(const GradKnotArgs<double>&, hipStream_t);                     // split rollout, pass 2
+  hipError_t (*bundle)(const BundleArgs<double>&, long, int ppw, hipStream_t);
+  hipError_t (*raw64)(const RawArgs<double>&, int ppw, hipStream_t);
+  hipError_t (*raw32)(const RawArgs<float>&, int ppw, hipStream_t);
 };
 
 const ModelVT* vt_acrobot_impact();
@@ -29,11 +33,33 @@ const ModelVT* vt_rocket_dynamics();
 const ModelVT* vt_rocket_projection();
 const ModelVT* vt_hopper();
 
-hipError_t launch_rocket64(const RocketArgs<double>&, hipStream_t);
-hipError_t launch_rocket32(const RocketArgs<float>&, hipStream_t);
+hipError_t launch_rocket64(const RocketArgs<double>&, int ppw, hipStream_t);
+hipError_t launch_rocket32(const RocketArgs<float>&, int ppw, hipStream_t);
 
 constexpr int OD_BLOCK = 64;   // one wavefront per workgroup: units are independent, no LDS
 
-inline dim3 od_grid(long n) { return dim3((unsigned)((n + OD_BLOCK - 1) / OD_BLOCK)); }
+// Lane mapping.  Every lane runs its own interior-point loop, so a wavefront is as slow as its slowest
+// lane (iteration counts differ with the contact mode).  When the batch is too small to fill the
+// chip (256 CUs x 4 SIMDs), fewer problems per wavefront (ppw < 64, remaining lanes idle) spread
+// the work over more SIMDs and shorten each wave's critical path; large batches use all 64 lanes.
+struct LaneMap {
+  int ppw;                                  // problems per wavefront, power of two in [1, 64]
+  int lds;                                  // 1: KKT factors live in LDS (latency variant)
+  // thread t of a block: wavefront t/64, lane t%64 (blocks are 1 or 4 wavefronts)
+  __host__ __device__ long problem(unsigned block, unsigned thread, unsigned block_threads = 64) const {
+    return ((long)block * (block_threads / 64) + thread / 64) * ppw + (thread & 63);
+  }
+  __host__ __device__ bool active(unsigned thread) const { return (int)(thread & 63) < ppw; }
+};
+
+inline int od_auto_ppw(long n) {
+  // Measured on MI355X (profiles/): this fp64, register-heavy instruction stream stops scaling at
+  // about 256 resident wavefronts chip-wide (more wavefronts only add issue stalls), so aim at 256
+  // wavefronts and pack more problems per wavefront only beyond that.
+  long p = 1;
+  while (p < 64 && n / p > 256) p <<= 1;
+  return (int)p;
+}
+inline dim3 od_grid(long n, int ppw) { return dim3((unsigned)((n + ppw - 1) / ppw)); }
 
 }  // namespace od

@@ -82,6 +82,10 @@ class ImplicitDynamics:
         if self.device.type == "cuda":
             self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def set_launch_config(self, ppw=0, split_rollout=-1):
+        """launch tuning (0 / -1 = automatic), see od_set_launch_config"""
+        self.lib.check(self.lib.cdll.od_set_launch_config(self._h, int(ppw), int(split_rollout)))
+
     def synchronize(self):
         self.lib.check(self.lib.cdll.od_synchronize(self._h))
 

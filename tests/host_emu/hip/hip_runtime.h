@@ -12,6 +12,7 @@
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
+#define __shared__ thread_local
 
 struct dim3 {
   unsigned x, y, z;

@@ -116,7 +116,11 @@ def check_rollout(oracle, lib, device, B, T, name="hopper", u_sigma=0.3):
     t = min(T - 1, 3)
     D, DX, DU, st1, it1 = im.step_grad(X[:, t], torch.tensor(U[:, t]))
     assert torch.equal(D, X[:, t + 1])
-    assert torch.equal(DX, A[:, :, t]) and torch.equal(DU, Bm[:, :, t])
+    # the split rollout differentiates in a second pass (same iterate, same clamp): identical up to
+    # the compiler's instruction scheduling / FMA contraction of the two kernels
+    okk = ((st1 & 3) == 3).cpu().numpy()
+    assert_grad_close(np.concatenate([A[:, :, t].cpu().numpy(), Bm[:, :, t].cpu().numpy()], 1),
+                      np.concatenate([DX.cpu().numpy(), DU.cpu().numpy()], 1), okk, "rollout vs step_grad")
     # gradients along the trajectory vs the oracle on the oracle's states (first knots)
     G = np.concatenate([An[:, :, 0], Bn[:, :, 0]], 1)
     Go = np.concatenate([Ao[:, :, 0], Bo[:, :, 0]], 1)
