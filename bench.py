@@ -172,8 +172,11 @@ def main():
                        "units_per_step_per_gpu": units_per_rank, "parallelism": "rollouts sharded x%d, no collective%s" % (world, " + all-gather(x+,A,B)" if args.gather else "")},
             "roofline": {"bound": "mfma", "bound_detail": "fp64 compute roof (FP64 vector = FP64 matrix peak on MI355X); no MFMA-shaped work on this path",
                          "achieved": ach_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / FP64_PEAK_TFLOPS,
-                         "traffic": None,
-                         "kernel": "k_rollout<Model_hopper,double>", "kernel_ms": kernel_ms,
+                         # HBM bytes per od_rollout from the rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE over both
+                         # kernels, profiles/r1_pmc_summary.txt); only valid for the default workload
+                         "traffic": (458.4e6 if (B == 4096 and T == 100 and not args.gather) else None),
+                         "traffic_note": "bytes per launch pair, measured offline with rocprofv3 --pmc (profiles/); algorithmic = %d" % (algorithmic_bytes_per_unit() * units_per_rank),
+                         "kernel": "od_rollout = k_rollout_state<Model_hopper,double> (99 %) + k_grad_knots<Model_hopper,double>", "kernel_ms": kernel_ms,
                          "algorithmic_flops_per_unit": F, "mean_iterations_to_kappa_eval": it_eval, "max_iterations": it_max,
                          "hbm_algorithmic_GBps": ach_gbs, "hbm_frac": ach_gbs / HBM_PEAK_GBS},
             "solver_status_counts": {"converged(7)": stc[7], "other": int(sum(stc) - stc[7])},

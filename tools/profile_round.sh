@@ -1,0 +1,14 @@
+# usage (on the GPU box, via gpurun): bash tools/profile_round.sh r1
+# kernel-trace + stats of the bench command, then two separate PMC passes for HBM traffic
+TAG=${1:-r1}
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
+python $R/bench.py --steps 10 --warmup 2 > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_traced.json 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/pmc_sq -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+find $O -name "*.csv" | head -30
+cat $O/bench.json
