@@ -224,16 +224,24 @@ def emit_oracle_table(m: ModelSpec) -> str:
 # --------------------------------------------------------------------------------------
 # device flavour
 # --------------------------------------------------------------------------------------
+def _lit(c):
+    return "T(%r)" % float(c)
+
+
 class _Elim:
     """Static-order sparse Gaussian elimination on the structural pattern of rz, preceded by
-    runtime row/column role swaps for the second-order-cone blocks, followed by a dense tail."""
+    runtime row/column role swaps for the second-order-cone blocks, followed by a dense tail.
 
-    def __init__(self, nz, pattern, order, floor_pivots=(), swaps=(), tail_last=()):
+    Entries whose value is a compile-time constant (the +-1 of slack / psi / tangential-velocity rows,
+    friction-free zeros, ...) are tracked and folded: no reciprocal, no multiply, no factor slot."""
+
+    def __init__(self, nz, pattern, order, floor_pivots=(), swaps=(), tail_last=(), const_entries=None):
         self.nz = nz
         self.order = list(order)
         self.swaps = list(swaps)
         pat = set(pattern)
-        self.init_zero = set()          # entries that exist only because of a swap union
+        cval = dict(const_entries or {})          # (i,j) -> float for compile-time constant entries
+        self.init_zero = set()
         self.swap_lines: List[str] = []
         S = self.swap_lines
         for k, ((ra, rb), (ca, cb)) in enumerate(self.swaps):
@@ -243,68 +251,126 @@ class _Elim:
             for j in cols:
                 for i in (ra, rb):
                     if (i, j) not in pat:
-                        pat.add((i, j)); self.init_zero.add((i, j))
+                        pat.add((i, j)); self.init_zero.add((i, j)); cval[(i, j)] = 0.0
+                if cval.get((ra, j)) is not None and cval.get((ra, j)) == cval.get((rb, j)):
+                    continue
+                cval.pop((ra, j), None); cval.pop((rb, j), None)
                 S.append("{ const T u_ = a_%d_%d, w_ = a_%d_%d; a_%d_%d = sw%d ? w_ : u_; a_%d_%d = sw%d ? u_ : w_; }"
                          % (ra, j, rb, j, ra, j, k, rb, j, k))
             rows = sorted({i for (i, j) in pat if j in (ca, cb)})
             for i in rows:
                 for j in (ca, cb):
                     if (i, j) not in pat:
-                        pat.add((i, j)); self.init_zero.add((i, j))
+                        pat.add((i, j)); self.init_zero.add((i, j)); cval[(i, j)] = 0.0
+                if cval.get((i, ca)) is not None and cval.get((i, ca)) == cval.get((i, cb)):
+                    continue
+                cval.pop((i, ca), None); cval.pop((i, cb), None)
                 S.append("{ const T u_ = a_%d_%d, w_ = a_%d_%d; a_%d_%d = sw%d ? w_ : u_; a_%d_%d = sw%d ? u_ : w_; }"
                          % (i, ca, i, cb, i, ca, k, i, cb, k))
         self.pattern0 = set(pat)
+        self.const0 = dict(cval)                  # constants at the start of the elimination
         rows = list(range(nz))
         cols = list(range(nz))
         self.slots = 0
         self.fac_lines: List[str] = []
-        self.fwd = []   # (pr, [(row i, slot l)])
-        self.bwd = []   # (pr, pc, slot ip, [(col j, slot u)])
+        # solve program: values are either ('c', float) or ('s', slot)
+        self.fwd = []   # (pr, [(row i, val)])
+        self.bwd = []   # (pr, pc, ipval, [(col j, val)])
         L = self.fac_lines
+
+        def ref(i, j):
+            return _lit(cval[(i, j)]) if (i, j) in cval else "a_%d_%d" % (i, j)
+
         for (pr, pc) in self.order:
             assert (pr, pc) in pat, ("structurally zero pivot", pr, pc)
             assert pr in rows and pc in cols
             rows.remove(pr)
             cols.remove(pc)
-            ip = self._slot()
-            if (pr, pc) in floor_pivots:
-                L.append("{ const T ip_ = od_rcp(od_max(a_%d_%d, T(OD_PIVOT_FLOOR))); f.v[%d] = ip_;" % (pr, pc, ip))
+            L.append("{")
+            if (pr, pc) in cval:
+                assert cval[(pr, pc)] != 0.0
+                ipc = 1.0 / cval[(pr, pc)]
+                ipval = ("c", ipc)
             else:
-                L.append("{ const T ip_ = od_rcp(a_%d_%d); f.v[%d] = ip_;" % (pr, pc, ip))
-            fw = []
-            prow = [j for j in cols if (pr, j) in pat]
-            for i in rows:
-                if (i, pc) not in pat:
-                    continue
+                ipc = None
                 sl = self._slot()
-                L.append("  { const T l_ = a_%d_%d * ip_; f.v[%d] = l_;" % (i, pc, sl))
-                fw.append((i, sl))
-                for j in prow:
-                    if (i, j) in pat:
-                        L.append("    a_%d_%d -= l_ * a_%d_%d;" % (i, j, pr, j))
+                if (pr, pc) in floor_pivots:
+                    L.append("  const T ip_ = od_rcp(od_max(a_%d_%d, T(OD_PIVOT_FLOOR))); f.v[%d] = ip_;" % (pr, pc, sl))
+                else:
+                    L.append("  const T ip_ = od_rcp(a_%d_%d); f.v[%d] = ip_;" % (pr, pc, sl))
+                ipval = ("s", sl)
+            fw = []
+            prow = [j for j in cols if (pr, j) in pat and cval.get((pr, j)) != 0.0]
+            for i in rows:
+                if (i, pc) not in pat or cval.get((i, pc)) == 0.0:
+                    continue
+                # multiplier l = a_i_pc * ip
+                if (i, pc) in cval and ipc is not None:
+                    lc = cval[(i, pc)] * ipc
+                    lval = ("c", lc)
+                    lexpr = None
+                else:
+                    lc = None
+                    sl = self._slot()
+                    if ipc is not None:
+                        if ipc == 1.0:
+                            lexpr0 = "a_%d_%d" % (i, pc)
+                        elif ipc == -1.0:
+                            lexpr0 = "-a_%d_%d" % (i, pc)
+                        else:
+                            lexpr0 = "a_%d_%d * %s" % (i, pc, _lit(ipc))
                     else:
-                        L.append("    a_%d_%d = -(l_ * a_%d_%d);" % (i, j, pr, j))
+                        lexpr0 = "%s * ip_" % ref(i, pc)
+                    L.append("  { const T l_ = %s; f.v[%d] = l_;" % (lexpr0, sl))
+                    lval = ("s", sl)
+                    lexpr = "l_"
+                fw.append((i, lval))
+                for j in prow:
+                    uc = cval.get((pr, j))
+                    # product l * u
+                    if lc is not None and uc is not None:
+                        pc_ = lc * uc
+                        if (i, j) in pat and (i, j) not in cval:
+                            L.append("    a_%d_%d -= %s;" % (i, j, _lit(pc_)))
+                        else:
+                            cval[(i, j)] = cval.get((i, j), 0.0) - pc_
+                            pat.add((i, j))
+                        continue
+                    if lc is not None:
+                        prod = ("a_%d_%d" % (pr, j)) if lc == 1.0 else (("-a_%d_%d" % (pr, j)) if lc == -1.0 else "%s * a_%d_%d" % (_lit(lc), pr, j))
+                    elif uc is not None:
+                        prod = "l_" if uc == 1.0 else ("-l_" if uc == -1.0 else "l_ * %s" % _lit(uc))
+                    else:
+                        prod = "l_ * a_%d_%d" % (pr, j)
+                    if (i, j) in pat:
+                        if (i, j) in cval:      # constant becomes runtime
+                            c0 = cval.pop((i, j))
+                            L.append("    a_%d_%d = %s - (%s);" % (i, j, _lit(c0), prod))
+                        else:
+                            L.append("    a_%d_%d -= %s;" % (i, j, prod))
+                    else:
+                        L.append("    a_%d_%d = -(%s);" % (i, j, prod))
                         pat.add((i, j))
-                L.append("  }")
+                if lexpr is not None:
+                    L.append("  }")
             us = []
             for j in prow:
-                sl = self._slot()
-                L.append("  f.v[%d] = a_%d_%d;" % (sl, pr, j))
-                us.append((j, sl))
+                if (pr, j) in cval:
+                    us.append((j, ("c", cval[(pr, j)])))
+                else:
+                    sl = self._slot()
+                    L.append("  f.v[%d] = a_%d_%d;" % (sl, pr, j))
+                    us.append((j, ("s", sl)))
             L.append("}")
             self.fwd.append((pr, fw))
-            self.bwd.append((pr, pc, ip, us))
+            self.bwd.append((pr, pc, ipval, us))
         self.tail_rows = rows
-        # dense tail: cone leftovers first, configuration unknowns last.  In sticking / statically
-        # indeterminate contact modes the leftover columns carry information only at the scale of the
-        # vanishing cone variables (~1e-18); eliminating them before they are mixed with the O(1)
-        # configuration block keeps that scale intact (same effect as the reference's full partial
-        # pivoting), see DESIGN.md "KKT elimination".
         self.tail_cols = [c for c in cols if c not in tail_last] + [c for c in cols if c in tail_last]
         self.m = len(rows)
         self.tail_base = self.slots
         self.slots += self.m * self.m
         self.final_pattern = pat
+        self.final_const = cval
 
     def _slot(self):
         s = self.slots
@@ -320,7 +386,9 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
     o.write("// Model %s: nz=%d ntheta=%d  (reference residual statement: see codegen/models.py)\n" % (n, m.nz, m.nth))
     o.write("#pragma once\n#include \"../od_math.h\"\n\nnamespace od {\n\n")
 
-    el = _Elim(m.nz, d.rz_nz, m.elim, set(m.floor_pivots), m.swaps, set(m.idx_zq) if (m.soc and m.kind == 'mech') else ())
+    const_entries = {(i, j): float(d.rz[i, j]) for (i, j) in d.rz_nz if d.rz[i, j].is_Number}
+    el = _Elim(m.nz, d.rz_nz, m.elim, set(m.floor_pivots), m.swaps,
+               set(m.idx_zq) if (m.soc and m.kind == 'mech') else (), const_entries)
     nnz = len(d.rz_nz)
     nnzth = len(d.rth_nz)
 
@@ -531,7 +599,7 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
         if (i, j) in el.init_zero:
             o.write("    T a_%d_%d = T(0);\n" % (i, j))
         else:
-            o.write("    T a_%d_%d;\n" % (i, j))
+            o.write("    T a_%d_%d = T(0);\n" % (i, j))
     for ln in el.swap_lines:
         o.write("    " + ln + "\n")
     for ln in el.fac_lines:
@@ -540,7 +608,9 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
         o.write("    T tl_[MTAIL * MTAIL];\n")
     for ii, i in enumerate(el.tail_rows):
         for jj, j in enumerate(el.tail_cols):
-            if (i, j) in el.final_pattern:
+            if (i, j) in el.final_const:
+                o.write("    tl_[%d] = %s;\n" % (ii + el.m * jj, _lit(el.final_const[(i, j)])))
+            elif (i, j) in el.final_pattern:
                 o.write("    tl_[%d] = a_%d_%d;\n" % (ii + el.m * jj, i, j))
             else:
                 o.write("    tl_[%d] = T(0);\n" % (ii + el.m * jj))
@@ -559,9 +629,22 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
         o.write("    T y_%d = b[%d];\n" % (i, i))
     for k, ((ra, rb), (ca, cb)) in enumerate(el.swaps):
         o.write("    { const T u_ = y_%d, w_ = y_%d; y_%d = f.sw[%d] ? w_ : u_; y_%d = f.sw[%d] ? u_ : w_; }\n" % (ra, rb, ra, k, rb, k))
+    def _mul(val, operand):
+        """code for val * operand; val = ('c', float) | ('s', slot)"""
+        if val[0] == "s":
+            return "f.v[%d] * %s" % (val[1], operand)
+        c = val[1]
+        if c == 1.0:
+            return operand
+        if c == -1.0:
+            return "-%s" % operand
+        return "%s * %s" % (_lit(c), operand)
+
     for (prw, fw) in el.fwd:
-        for (i, sl) in fw:
-            o.write("    y_%d -= f.v[%d] * y_%d;\n" % (i, sl, prw))
+        for (i, lval) in fw:
+            if lval[0] == "c" and lval[1] == 0.0:
+                continue
+            o.write("    y_%d -= %s;\n" % (i, _mul(lval, "y_%d" % prw)))
     if el.m > 0:
         o.write("    T t_[MTAIL];\n")
         for ii, i in enumerate(el.tail_rows):
@@ -570,9 +653,9 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
         o.write("    od_lu_solve<T, MTAIL>(tl_, f.piv, t_);\n")
         for jj, j in enumerate(el.tail_cols):
             o.write("    const T x_%d = t_[%d];\n" % (j, jj))
-    for (prw, pc, ip, us) in reversed(el.bwd):
-        terms = "".join(" - f.v[%d] * x_%d" % (sl, j) for (j, sl) in us)
-        o.write("    const T x_%d = (y_%d%s) * f.v[%d];\n" % (pc, prw, terms, ip))
+    for (prw, pc, ipval, us) in reversed(el.bwd):
+        terms = "".join(" - (%s)" % _mul(uv, "x_%d" % j) for (j, uv) in us if not (uv[0] == "c" and uv[1] == 0.0))
+        o.write("    const T x_%d = %s;\n" % (pc, _mul(ipval, "(y_%d%s)" % (prw, terms))))
     swapped = {}
     for k, ((ra, rb), (ca, cb)) in enumerate(el.swaps):
         swapped[ca] = (cb, k)

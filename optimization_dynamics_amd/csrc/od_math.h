@@ -56,6 +56,23 @@ OD_HD double od_rcp(double x) { return 1.0 / x; }
 OD_HD float od_rcp(float x) { return 1.0f / x; }
 #endif
 
+// reciprocal square root (seed + Newton steps on the device)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OD_EXACT_RCP)
+OD_HD double od_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) y = __builtin_fma(__builtin_fma(-0.5 * x * y, y, 0.5), y, y);
+  return y;
+}
+OD_HD float od_rsqrt(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  return __builtin_fmaf(__builtin_fmaf(-0.5f * x * y, y, 0.5f), y, y);
+}
+#else
+OD_HD double od_rsqrt(double x) { return 1.0 / sqrt(x); }
+OD_HD float od_rsqrt(float x) { return 1.0f / sqrtf(x); }
+#endif
+
 template <class T> OD_HD T od_min(T a, T b) { return a < b ? a : b; }
 template <class T> OD_HD T od_max(T a, T b) { return a > b ? a : b; }
 
@@ -86,11 +103,13 @@ template <class T, int N> OD_HD bool od_lu_factor(T* A, int* piv) {
     }
     piv[k] = p;
     ok = ok && (best > T(0));
+    // exchange rows k and p of the ACTIVE part only (columns >= k); the multipliers already stored
+    // in columns < k stay with their physical rows, and od_lu_solve replays the exchanges in order
 #pragma unroll
     for (int i = k + 1; i < N; ++i) {
       const bool sw = (p == i);
 #pragma unroll
-      for (int j = 0; j < N; ++j) {
+      for (int j = k; j < N; ++j) {
         const T u = A[k + N * j], w = A[i + N * j];
         A[k + N * j] = sw ? w : u;
         A[i + N * j] = sw ? u : w;
@@ -115,17 +134,14 @@ template <class T, int N> OD_HD void od_lu_solve(const T* A, const int* piv, T* 
   for (int k = 0; k < N; ++k) {
     const int p = piv[k];
 #pragma unroll
-    for (int i = k + 1; i < N; ++i) {
+    for (int i = k + 1; i < N; ++i) {          // exchange k of the factorisation ...
       const bool sw = (p == i);
       const T u = b[k], w = b[i];
       b[k] = sw ? w : u;
       b[i] = sw ? u : w;
     }
-  }
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-#pragma unroll
-    for (int i = k + 1; i < N; ++i) b[i] -= A[i + N * k] * b[k];
+    for (int i = k + 1; i < N; ++i) b[i] -= A[i + N * k] * b[k];   // ... then its elimination step
   }
 #pragma unroll
   for (int k = N - 1; k >= 0; --k) {

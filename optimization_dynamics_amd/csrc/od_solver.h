@@ -55,8 +55,7 @@ template <int N, class T> OD_HD T soc_step_one(const T* lam, const T* dlt, T tau
   for (int i = 1; i < N; ++i) { ll -= lam[i] * lam[i]; ld -= lam[i] * dlt[i]; }
   ll = od_max(ll, T(1e-25)) + eps;
   ld += eps;
-  const T sq = od_sqrt(ll);
-  const T isq = od_rcp(sq), ill = isq * isq;
+  const T isq = od_rsqrt(ll), ill = isq * isq;
   const T rs = ld * ill;
   const T c = (ld * isq + dlt[0]) * od_rcp(l0 * isq + T(1));
   T nv = T(0);
@@ -178,7 +177,9 @@ template <class M, class T> struct LdsFact {
 template <class M, class T, class Sink, class F>
 OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, bool want_grad, Sink& sink, int* iters, F& f) {
   constexpr bool CONES = (M::NORT + M::NSOC) > 0;
-  T r[M::NZ], zs[M::NZ], pre[M::NPRE], tr[M::NTR];
+  // state snapshot at (r_tol, kappa_eval): the whole z for raw solves, only the next configuration otherwise
+  constexpr int NSNAP = Sink::FULL_STATE ? M::NZ : M::NZQ;
+  T r[M::NZ], zs[NSNAP], pre[M::NPRE], tr[M::NTR];
   M::eval_pre(th, pre);
   M::eval_r(z, th, pre, tr, r);
   T r_vio = viol_eq<M>(r), k_vio = viol_bil<M>(r);
@@ -218,7 +219,7 @@ OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, boo
     }
     if (!eval_done && ((req && k_vio < o.kappa_eval) || last)) {
 #pragma unroll
-      for (int i = 0; i < M::NZ; ++i) zs[i] = z[i];
+      for (int i = 0; i < NSNAP; ++i) zs[i] = Sink::FULL_STATE ? z[i] : z[M::ZQ[i]];
       eval_done = true;
       iters[0] = it;
       if (!last) status |= OD_ST_EVAL_OK;
@@ -265,7 +266,7 @@ OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, boo
   }
   if (want_state) {
 #pragma unroll
-    for (int i = 0; i < M::NZ; ++i) z[i] = zs[i];
+    for (int i = 0; i < NSNAP; ++i) z[Sink::FULL_STATE ? i : M::ZQ[i]] = zs[i];
   }
   return status;
 }

@@ -36,6 +36,7 @@ template <class T> struct StepArgs {
 
 template <class M, class T> struct StepSink {
   static constexpr bool DEFER_GRAD = false;
+  static constexpr bool FULL_STATE = false;
   const StepArgs<T>& a;
   long b;
   OD_HD void defer(const T*, T) {}
@@ -144,6 +145,7 @@ template <class T> struct RolloutStateArgs {
 
 template <class M, class T> struct DeferSink {
   static constexpr bool DEFER_GRAD = true;
+  static constexpr bool FULL_STATE = false;
   const View<T>& zg;
   long k;
   OD_HD void grad(int, int, T) {}
@@ -225,6 +227,7 @@ template <class M, class T> OD_HD void unit_grad_knot(const GradKnotArgs<T>& ga,
 
 template <class T> struct NoGradSink {
   static constexpr bool DEFER_GRAD = false;
+  static constexpr bool FULL_STATE = false;
   OD_HD void grad(int, int, T) {}
   OD_HD void defer(const T*, T) {}
 };
@@ -274,6 +277,7 @@ template <class T> struct RawArgs {
 
 template <class M, class T> struct RawSink {
   static constexpr bool DEFER_GRAD = false;
+  static constexpr bool FULL_STATE = true;
   const RawArgs<T>& a;
   long b;
   OD_HD void defer(const T*, T) {}
@@ -314,6 +318,7 @@ template <class T> struct RocketArgs {
 // d(projected u)/du: 3 x 3 col-major kept in registers (column index is dynamic -> selects)
 template <class T> struct ProjSink {
   static constexpr bool DEFER_GRAD = false;
+  static constexpr bool FULL_STATE = true;
   T* d;
   OD_HD void defer(const T*, T) {}
   OD_HD void grad(int i, int c, T v) {
@@ -324,6 +329,7 @@ template <class T> struct ProjSink {
 // dz_dyn: x-columns go straight to dx, the three u-columns are collected for the chain product
 template <class T> struct RocketDynSink {
   static constexpr bool DEFER_GRAD = false;
+  static constexpr bool FULL_STATE = true;
   const RocketArgs<T>& a;
   long b;
   T* dyn_u;
