@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--gather", action="store_true", help="all-gather (x+, A, B) after every step (RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ppw", type=int, default=0, help="problems per wavefront (0 = library default)")
-    ap.add_argument("--split", type=int, default=-1, help="1/0: force the split (state pass + gradient pass) rollout on/off (-1 = library default)")
+    ap.add_argument("--wpb", type=int, default=0, help="wavefronts per workgroup of the solve pass: 1 or 4 (0 = library default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,8 +107,8 @@ def main():
 
     from optimization_dynamics_amd import ImplicitDynamics, hopper
     im = ImplicitDynamics(hopper, 0.05, r_tol=1e-8, kappa_eval_tol=1e-4, kappa_grad_tol=1e-3, device=dev)  # examples/hopper.jl:42
-    if args.ppw or args.split >= 0:
-        im.set_launch_config(args.ppw, args.split)
+    if args.ppw or args.wpb:
+        im.set_launch_config(args.ppw, args.wpb)
     B, T = args.batch, args.horizon
     x1, U = make_inputs(B, T, seed=rank)
     x1d = torch.tensor(x1, device=dev)

@@ -79,19 +79,18 @@ int od_set_friction(od_handle h, const double* mu, int n);
 int od_set_u_max(od_handle h, double u_max);
 int od_set_layout(od_handle h, int layout);
 int od_set_stream(od_handle h, void* hip_stream);
-/* launch tuning.  ppw: problems per 64-lane wavefront (power of two <= 64, 0 = automatic) -- a wavefront
- * is as slow as its slowest lane, so small batches are spread over more wavefronts.
- * split_rollout: 1 = od_rollout runs the state recursion first (recording each knot's gradient iterate)
- * and all T*B implicit gradients in a second, fully parallel launch; 0 = single fused launch;
- * -1 = automatic.  Results are identical either way. */
-int od_set_launch_config(od_handle h, int ppw, int split_rollout);
+/* launch tuning of the solve pass.  ppw: problems per 64-lane wavefront (power of two <= 64, 0 = automatic)
+ * -- a wavefront is as slow as its slowest lane, so small batches are spread over more wavefronts.
+ * waves_per_block: 1 or 4 wavefronts per workgroup (4 = one per SIMD of a CU), 0 = automatic. */
+int od_set_launch_config(od_handle h, int ppw, int waves_per_block);
 int od_synchronize(od_handle h);
 
 /* f (src/dynamics.jl:81-94) for B knots: d = [q2; q3].  x: 2nq, u: nu, d: 2nq per problem.
  * status, iters (2 ints per problem: iterations to kappa_eval / kappa_grad) may be NULL. */
 int od_step(od_handle h, long B, const void* x, const void* u, void* d, int* status, int* iters);
 
-/* f + fx + fu (src/dynamics.jl:81-128) in one solve per knot.  dx: 2nq x 2nq, du: 2nq x nu per
+/* f + fx + fu (src/dynamics.jl:81-128) with one interior-point solve per knot (two launches: the solves,
+ * then all implicit-function gradients; the handle owns the hand-over workspace).  dx: 2nq x 2nq, du: 2nq x nu per
  * problem, every entry written (the reference writes 3 blocks into a caller-zeroed matrix).
  * Any of d, dx, du may be NULL. */
 int od_step_grad(od_handle h, long B, const void* x, const void* u, void* d, void* dx, void* du,
@@ -103,7 +102,8 @@ int od_step_grad_compact(od_handle h, long B, const void* x, const void* u, void
                          int* status, int* iters);
 
 /* iLQR.rollout through f plus the derivative sweep through fx, fu (examples/acrobot.jl:92 and the
- * solver's per-knot fx/fu calls) for B trajectories of T steps, time recursion on device.
+ * solver's per-knot fx/fu calls) for B trajectories of T steps: launch 1 runs the time recursion on the
+ * device, launch 2 all T*B implicit gradients in parallel.
  * x1: 2nq per trajectory; U: nu per knot (T*B knots); X: 2nq per slot ((T+1)*B slots, slot 0 = x1);
  * A: 2nq x 2nq per knot; Bm: 2nq x nu per knot.  A, Bm, status (T*B), iters (2*T*B) may be NULL. */
 int od_rollout(od_handle h, long B, int T, const void* x1, const void* U, void* X, void* A, void* Bm,

@@ -119,8 +119,8 @@ struct od_handle_s {
   double h, fric[4], u_max;
   hipStream_t stream;
   int ppw;         // problems per wavefront; 0 = automatic (od_auto_ppw)
-  int split;       // rollouts: -1 automatic, 0 fused single pass, 1 split (state pass + gradient pass)
-  double* work;    // device workspace of the split rollout
+  int wpb;         // wavefronts per workgroup of the state pass: 0 automatic, 1 or 4
+  double* work;    // device workspace: gradient iterates handed from pass 1 to pass 2
   size_t work_elems;
   double* stage;   // device staging for the host scalar path
   size_t stage_elems;
@@ -145,22 +145,26 @@ template <class T> View<const T> mkcview(const void* p, long E, long K, int layo
 
 int ppw_of(const od_handle_s* h, long n) { return h->ppw > 0 ? h->ppw : od_auto_ppw(n); }
 
+// pass-1 launch shape: 4 wavefronts per workgroup (one per SIMD) while that still spreads the batch over
+// the chip, problems per wavefront from od_auto_ppw (aims at ~256 resident wavefronts)
 LaunchCfg cfg_of(const od_handle_s* h, long n) {
   LaunchCfg c;
   c.ppw = ppw_of(h, n);
-  c.wpb = 1;
-  c.lds = 0;
+  c.wpb = h->wpb > 0 ? h->wpb : 4;
   return c;
 }
 
-// split rollout, state pass: 4 wavefronts per workgroup (one per SIMD of a CU)
-LaunchCfg cfg_state(const od_handle_s* h, long n) {
-  LaunchCfg c;
-  c.wpb = 4;
-  c.lds = 0;
-  if (h->ppw > 0) c.ppw = h->ppw;
-  else c.ppw = od_auto_ppw(n);
-  return c;
+int ensure_work(od_handle_s* h, size_t elems) {
+  if (h->work_elems >= elems) return OD_OK;
+  if (h->work) {
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(OD_ERR_HIP, "hipStreamSynchronize failed");
+    (void)hipFree(h->work);
+    h->work = nullptr;
+    h->work_elems = 0;
+  }
+  if (hipMalloc((void**)&h->work, elems * sizeof(double)) != hipSuccess) return fail(OD_ERR_HIP, "hipMalloc (gradient workspace) failed");
+  h->work_elems = elems;
+  return OD_OK;
 }
 
 // with cones and a finite undercut the centering floor depends on kappa_tol, so the two
@@ -188,6 +192,7 @@ StepArgs<double> step_args(od_handle_s* h, long B, long K, const void* x, const 
   a.dq3 = mkview<double>(dq3, nq * (n + nu), K, L);
   a.status = mkview<int>(status, 1, K, L);
   a.iters = mkview<int>(iters, 2, K, L);
+  a.zg.p = nullptr; a.zg.se = 0; a.zg.sb = 0;
   a.want_grad = want_grad;
   a.d_skip_q2 = 0;
   return a;
@@ -200,25 +205,42 @@ int check_mech(od_handle_s* h, const char* fn) {
   return OD_OK;
 }
 
+// pass 2 over K knots whose states live in `xstate` (slot k) -- shared by od_step_grad and od_rollout
+int run_grad_pass(od_handle_s* h, StepArgs<double> g, long K, View<const double> xstate) {
+  g.B = K;
+  g.x = xstate;
+  g.d.p = nullptr;
+  g.iters.p = nullptr;
+  OD_HIP(h->vt->grad_knots(g, h->stream));
+  return OD_OK;
+}
+
 int run_step(od_handle_s* h, const char* fn, long B, const void* x, const void* u, void* d, void* dx, void* du,
-             void* dq3, int* status, int* iters, int want_grad) {
+             void* dq3, int* status, int* iters, int want_grad, int d_skip_q2 = 0) {
   if (int rc = check_mech(h, fn)) return rc;
   if (B <= 0) return OD_OK;
   if (!x || (h->vt->nu > 0 && !u)) return fail(OD_ERR_INVALID, std::string(fn) + ": null input");
   StepArgs<double> a = step_args(h, B, B, x, u, d, dx, du, dq3, status, iters, want_grad);
-  if (want_grad && !fusable(h)) {
-    // two passes, exactly like the reference's eval_sim / grad_sim pair
-    StepArgs<double> e = a;
-    e.want_grad = 0; e.dx.p = nullptr; e.du.p = nullptr; e.dq3.p = nullptr;
-    OD_HIP(h->vt->step(e, cfg_of(h, B), h->stream));
-    StepArgs<double> g = a;
-    g.d.p = nullptr; g.opts.kappa_eval = g.opts.kappa_grad;
-    g.status.p = nullptr; g.iters.p = nullptr;
-    OD_HIP(h->vt->step(g, cfg_of(h, B), h->stream));
+  a.d_skip_q2 = d_skip_q2;
+  if (!want_grad) {
+    OD_HIP(h->vt->step_state(a, cfg_of(h, B), h->stream));
     return OD_OK;
   }
-  OD_HIP(h->vt->step(a, cfg_of(h, B), h->stream));
-  return OD_OK;
+  if (int rc = ensure_work(h, (size_t)(h->vt->nz + 1) * (size_t)B)) return rc;
+  a.zg = mkview<double>(h->work, h->vt->nz + 1, B, OD_LAYOUT_BATCH_MINOR);
+  if (!fusable(h)) {
+    // eval_sim and grad_sim iterate differently (finite undercut): run them separately like the reference
+    StepArgs<double> e = a;
+    e.want_grad = 0;
+    OD_HIP(h->vt->step_state(e, cfg_of(h, B), h->stream));
+    StepArgs<double> g = a;
+    g.d.p = nullptr; g.status.p = nullptr; g.iters.p = nullptr;
+    g.opts.kappa_eval = g.opts.kappa_grad;
+    OD_HIP(h->vt->step_state(g, cfg_of(h, B), h->stream));
+  } else {
+    OD_HIP(h->vt->step_state(a, cfg_of(h, B), h->stream));
+  }
+  return run_grad_pass(h, a, B, a.x);
 }
 
 }  // namespace
@@ -309,7 +331,7 @@ int od_create(int model, int dtype, const od_options* opts, double dt, od_handle
   h->u_max = 12.5;   // examples/rocket.jl:16
   h->stream = nullptr;
   h->ppw = 0;
-  h->split = -1;
+  h->wpb = 0;
   h->work = nullptr;
   h->work_elems = 0;
   h->stage = nullptr;
@@ -361,11 +383,11 @@ int od_set_stream(od_handle h, void* s) {
   h->stream = (hipStream_t)s;
   return OD_OK;
 }
-int od_set_launch_config(od_handle h, int ppw, int split_rollout) {
-  if (!h || ppw < 0 || ppw > 64 || (ppw & (ppw - 1)) || split_rollout < -1 || split_rollout > 1)
-    return fail(OD_ERR_INVALID, "od_set_launch_config: ppw = 0 (auto) or a power of two <= 64; split_rollout in {-1, 0, 1}");
+int od_set_launch_config(od_handle h, int ppw, int waves_per_block) {
+  if (!h || ppw < 0 || ppw > 64 || (ppw & (ppw - 1)) || !(waves_per_block == 0 || waves_per_block == 1 || waves_per_block == 4))
+    return fail(OD_ERR_INVALID, "od_set_launch_config: ppw = 0 (auto) or a power of two <= 64; waves_per_block in {0, 1, 4}");
   h->ppw = ppw;
-  h->split = split_rollout;
+  h->wpb = waves_per_block;
   return OD_OK;
 }
 int od_synchronize(od_handle h) {
@@ -385,18 +407,13 @@ int od_step_grad(od_handle h, long B, const void* x, const void* u, void* d, voi
 int od_step_grad_compact(od_handle h, long B, const void* x, const void* u, void* q3, void* dq3, int* status, int* iters) {
   if (int rc = check_mech(h, "od_step_grad_compact")) return rc;
   if (B <= 0) return OD_OK;
-  // q3 is the second half of d: give the d view an offset so that rows nq.. land in q3
-  const int nq = h->vt->nq;
-  StepArgs<double> a = step_args(h, B, B, x, u, nullptr, nullptr, nullptr, dq3, status, iters, dq3 ? 1 : 0);
+  // q3 is the second half of d: shift the d view so that element nq+i of the virtual d lands on q3[i]
+  void* dshift = nullptr;
   if (q3) {
-    View<double> v = mkview<double>(q3, nq, B, h->layout);
-    v.p -= (long)nq * v.se;   // element nq+i of the virtual d vector -> element i of q3
-    a.d = v;
-    a.d_skip_q2 = 1;
+    View<double> v = mkview<double>(q3, h->vt->nq, B, h->layout);
+    dshift = v.p - (long)h->vt->nq * v.se;
   }
-  if (a.want_grad && !fusable(h)) return fail(OD_ERR_UNSUPPORTED, "od_step_grad_compact: finite undercut with kappa_eval != kappa_grad; use od_step + od_step_grad");
-  OD_HIP(h->vt->step(a, cfg_of(h, B), h->stream));
-  return OD_OK;
+  return run_step(h, "od_step_grad_compact", B, x, u, dshift, nullptr, nullptr, dq3, status, iters, dq3 ? 1 : 0, 1);
 }
 
 int od_rollout(od_handle h, long B, int T, const void* x1, const void* U, void* X, void* A, void* Bm, int* status, int* iters) {
@@ -409,42 +426,21 @@ int od_rollout(od_handle h, long B, int T, const void* x1, const void* U, void* 
   const int want_grad = (A || Bm) ? 1 : 0;
   RolloutArgs<double> r;
   r.s = step_args(h, B, K, x1, U, nullptr, A, Bm, nullptr, status, iters, want_grad);
-  // X has (T+1)*B slots; knot k's d goes to slot k + B
+  // X has (T+1)*B slots; knot k's d = [q2; q3] goes to slot k + B
   View<double> xv = mkview<double>(X, n, (long)(T + 1) * B, h->layout);
   r.x0 = xv;
-  View<double> dv = xv;
-  dv.p += (long)B * dv.sb;
-  r.s.d = dv;
+  r.s.d = xv;
+  r.s.d.p += (long)B * xv.sb;
   r.Tn = T;
-  const bool split = want_grad && (h->split >= 0 ? h->split != 0 : true);
-  if (!split) {
-    OD_HIP(h->vt->rollout(r, cfg_of(h, B), h->stream));
-    return OD_OK;
+  if (want_grad) {
+    if (int rc = ensure_work(h, (size_t)(nz + 1) * (size_t)K)) return rc;
+    r.s.zg = mkview<double>(h->work, nz + 1, K, OD_LAYOUT_BATCH_MINOR);
   }
-  // pass 1: state recursion (records the gradient iterate of every knot); pass 2: all gradients
-  const size_t need = (size_t)(nz + 1) * (size_t)K;
-  if (h->work_elems < need) {
-    if (h->work) { OD_HIP(hipStreamSynchronize(h->stream)); (void)hipFree(h->work); h->work = nullptr; h->work_elems = 0; }
-    OD_HIP(hipMalloc((void**)&h->work, need * sizeof(double)));
-    h->work_elems = need;
-  }
-  RolloutStateArgs<double> rs;
-  rs.r = r;
-  rs.r.s.dx.p = nullptr; rs.r.s.du.p = nullptr; rs.r.s.dq3.p = nullptr;
-  rs.zg = mkview<double>(h->work, nz + 1, K, OD_LAYOUT_BATCH_MINOR);
-  OD_HIP(h->vt->rollout_state(rs, cfg_state(h, B), h->stream));
-  GradKnotArgs<double> g;
-  g.s = r.s;
-  g.s.B = K;
+  OD_HIP(h->vt->rollout_state(r, cfg_of(h, B), h->stream));          // pass 1: time recursion
+  if (!want_grad) return OD_OK;
   View<const double> xin;
-  xin.p = xv.p; xin.se = xv.se; xin.sb = xv.sb;     // state of knot k = slot k of X
-  g.s.x = xin;
-  g.s.d.p = nullptr;
-  g.s.iters.p = nullptr;
-  g.zg.p = h->work; g.zg.se = K; g.zg.sb = 1;
-  g.K = K;
-  OD_HIP(h->vt->grad_knots(g, h->stream));
-  return OD_OK;
+  xin.p = xv.p; xin.se = xv.se; xin.sb = xv.sb;                        // state of knot k = slot k of X
+  return run_grad_pass(h, r.s, K, xin);                                // pass 2: all T*B gradients
 }
 
 size_t od_bundle_workspace_bytes(od_handle h, long B, int N) {

@@ -13,11 +13,11 @@ template <class T> __global__ __launch_bounds__(OD_BLOCK) void k_rocket(RocketAr
 }
 
 hipError_t launch_rocket64(const RocketArgs<double>& a, int ppw, hipStream_t s) {
-  hipLaunchKernelGGL((k_rocket<double>), od_grid(a.B, ppw), dim3(OD_BLOCK), 0, s, a, LaneMap{ppw, 0});
+  hipLaunchKernelGGL((k_rocket<double>), od_grid(a.B, ppw), dim3(OD_BLOCK), 0, s, a, LaneMap{ppw});
   return hipGetLastError();
 }
 hipError_t launch_rocket32(const RocketArgs<float>& a, int ppw, hipStream_t s) {
-  hipLaunchKernelGGL((k_rocket<float>), od_grid(a.B, ppw), dim3(OD_BLOCK), 0, s, a, LaneMap{ppw, 0});
+  hipLaunchKernelGGL((k_rocket<float>), od_grid(a.B, ppw), dim3(OD_BLOCK), 0, s, a, LaneMap{ppw});
   return hipGetLastError();
 }
 

@@ -161,19 +161,6 @@ OD_HD bool eval_factor(const T* z, const T* th, const T* pre, const T* tr, T reg
 //
 // z: in = initial guess, out = iterate at (r_tol, kappa_eval) convergence (or the last iterate).
 // Returns status bits; iters[0] = iterations to kappa_eval, iters[1] = iterations to kappa_grad.
-// Factor storage in LDS: element k of this lane lives at p[k * stride] (stride = lane slots of the
-// workgroup), i.e. consecutive lanes hit consecutive 8-byte words -> conflict-free ds_read/write_b64.
-template <class T> struct StridedVec {
-  T* p;
-  int stride;
-  OD_HD T& operator[](int k) const { return p[(long)k * stride]; }
-};
-template <class M, class T> struct LdsFact {
-  StridedVec<T> v;
-  int piv[M::MTAIL > 0 ? M::MTAIL : 1];
-  bool sw[M::NSWAP > 0 ? M::NSWAP : 1];
-};
-
 template <class M, class T, class Sink, class F>
 OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, bool want_grad, Sink& sink, int* iters, F& f) {
   constexpr bool CONES = (M::NORT + M::NSOC) > 0;

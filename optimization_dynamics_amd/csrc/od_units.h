@@ -16,7 +16,13 @@ template <class T> struct View {
   OD_HD bool ok() const { return p != nullptr; }
 };
 
-// ---- f / fx / fu fused (src/dynamics.jl:81-128) ----------------------------------------------
+// ---- f / fx / fu (src/dynamics.jl:81-128) ------------------------------------------------------
+// Two passes.  Pass 1 ("state"): the interior-point solve of every knot (sequential in t for
+// rollouts), which records per knot the iterate z_g at which the reference's grad simulator would
+// stop and the clamp differentiate_solution! would use ((nz+1) doubles).  Pass 2 ("grad"): the
+// implicit-function solve of every knot, one lane per knot, fully parallel.  The gradient of knot t
+// does not feed knot t+1, so it is off the rollout's critical path and its arrays are out of the
+// solve loop's register budget.
 template <class T> struct StepArgs {
   long B;
   T h;
@@ -30,10 +36,12 @@ template <class T> struct StepArgs {
   View<T> dq3;       // compact nq x (2nq+nu) col-major = d q3/d(q1,q2,u) (alternative to dx/du)
   View<int> status;  // bit0 eval converged, bit1 grad converged, bit2 factorisation ok
   View<int> iters;   // 2 per problem: iterations to kappa_eval / kappa_grad
+  View<T> zg;        // workspace, nz+1 per problem: gradient iterate and clamp (pass 1 -> pass 2)
   int want_grad;
   int d_skip_q2;     // 1: only rows nq..2nq of d are written (compact q3 output)
 };
 
+// pass-2 output: dq3/d(q1,q2,u) scattered into the reference's dx / du layout (and/or compact dq3)
 template <class M, class T> struct StepSink {
   static constexpr bool DEFER_GRAD = false;
   static constexpr bool FULL_STATE = false;
@@ -48,101 +56,7 @@ template <class M, class T> struct StepSink {
   }
 };
 
-// one knot: x=[q1;q2], u -> d=[q2;q3], dx, du.  Returns status.
-template <class M, class T, class F>
-OD_HD int unit_step_core(const StepArgs<T>& a, long b, const T* xin, const T* uin, T* q3out, F& f) {
-  constexpr int nq = M::NQ, n = 2 * M::NQ;
-  T th[M::NTH], z[M::NZ];
-  mech_setup<M>(xin, xin + nq, uin, a.fric, a.h, th, z);
-  StepSink<M, T> sink{a, b};
-  int it[2];
-  const int st = ip_step_grad<M, T>(a.opts, th, z, true, a.want_grad != 0, sink, it, f);
-#pragma unroll
-  for (int i = 0; i < nq; ++i) q3out[i] = z[M::ZQ[i]];
-  if (a.d.ok()) {
-#pragma unroll
-    for (int i = 0; i < nq; ++i) {
-      if (!a.d_skip_q2) a.d.at(i, b) = xin[nq + i];
-      a.d.at(nq + i, b) = q3out[i];
-    }
-  }
-  if (a.want_grad) {
-    if (a.dx.ok()) {   // constant blocks of fx: [0 I] on top, rows nq.. written by the sink
-#pragma unroll
-      for (int c = 0; c < n; ++c) {
-#pragma unroll
-        for (int i = 0; i < nq; ++i) a.dx.at(i + n * c, b) = (c == nq + i) ? T(1) : T(0);
-      }
-    }
-    if (a.du.ok()) {
-#pragma unroll
-      for (int c = 0; c < M::NU; ++c) {
-#pragma unroll
-        for (int i = 0; i < nq; ++i) a.du.at(i + n * c, b) = T(0);
-      }
-    }
-  }
-  if (a.status.ok()) a.status.at(0, b) = st;
-  if (a.iters.ok()) { a.iters.at(0, b) = it[0]; a.iters.at(1, b) = it[1]; }
-  return st;
-}
-
-template <class M, class T, class F> OD_HD void unit_step_grad(const StepArgs<T>& a, long b, F& f) {
-  constexpr int nq = M::NQ, n = 2 * M::NQ;
-  T x[n], u[M::NU > 0 ? M::NU : 1], q3[nq];
-#pragma unroll
-  for (int i = 0; i < n; ++i) x[i] = a.x.at(i, b);
-#pragma unroll
-  for (int i = 0; i < M::NU; ++i) u[i] = a.u.at(i, b);
-  unit_step_core<M, T>(a, b, x, u, q3, f);
-}
-template <class M, class T> OD_HD void unit_step_grad(const StepArgs<T>& a, long b) {
-  typename M::template Fact<T> f;
-  unit_step_grad<M, T>(a, b, f);
-}
-
-// ---- rollout: T sequential steps per trajectory, state carried in registers ------------------
-// problem index for per-knot outputs is (t*B + b): X has T+1 slots, the rest T slots.
-template <class T> struct RolloutArgs {
-  StepArgs<T> s;     // x = x1 (2nq per trajectory); u/d/dx/du/dq3/status/iters are per-knot views
-  View<T> x0;        // slot 0 of X (receives a copy of x1)
-  int Tn;
-};
-
-template <class M, class T, class F> OD_HD void unit_rollout(const RolloutArgs<T>& ra, long b, F& f) {
-  constexpr int nq = M::NQ, n = 2 * M::NQ;
-  const StepArgs<T>& a = ra.s;
-  T x[n], u[M::NU > 0 ? M::NU : 1], q3[nq];
-#pragma unroll
-  for (int i = 0; i < n; ++i) x[i] = a.x.at(i, b);
-  if (ra.x0.ok()) {
-#pragma unroll
-    for (int i = 0; i < n; ++i) ra.x0.at(i, b) = x[i];
-  }
-  for (int t = 0; t < ra.Tn; ++t) {
-    const long k = (long)t * a.B + b;
-#pragma unroll
-    for (int i = 0; i < M::NU; ++i) u[i] = a.u.at(i, k);
-    unit_step_core<M, T>(a, k, x, u, q3, f);
-#pragma unroll
-    for (int i = 0; i < nq; ++i) { x[i] = x[nq + i]; x[nq + i] = q3[i]; }
-  }
-}
-template <class M, class T> OD_HD void unit_rollout(const RolloutArgs<T>& ra, long b) {
-  typename M::template Fact<T> f;
-  unit_rollout<M, T>(ra, b, f);
-}
-
-// ---- split rollout: (1) state recursion recording the gradient iterate, (2) gradients per knot -----
-// The time recursion only needs q3; the implicit gradient of knot t does not feed knot t+1.  Pass 1
-// keeps the critical path short (no rtheta / gradient right-hand sides in its register budget) and
-// stores, per knot, the iterate z_g at which the reference's grad simulator would have stopped and
-// the clamp it would have used.  Pass 2 is embarrassingly parallel over all T*B knots.
-template <class T> struct RolloutStateArgs {
-  RolloutArgs<T> r;     // r.s.dx / du / dq3 unused here
-  View<T> zg;           // NZ + 1 per knot: z at the gradient iterate, then the clamp reg
-};
-
+// pass-1 sink: record where the gradient has to be taken
 template <class M, class T> struct DeferSink {
   static constexpr bool DEFER_GRAD = true;
   static constexpr bool FULL_STATE = false;
@@ -156,47 +70,71 @@ template <class M, class T> struct DeferSink {
   }
 };
 
-template <class M, class T> OD_HD void unit_rollout_state(const RolloutStateArgs<T>& ra, long b) {
+// pass 1 for one knot k given its state and control in registers; returns q3 in q3out
+template <class M, class T>
+OD_HD void knot_state(const StepArgs<T>& a, long k, const T* xin, const T* uin, T* q3out) {
+  constexpr int nq = M::NQ;
+  T th[M::NTH], z[M::NZ];
+  mech_setup<M>(xin, xin + nq, uin, a.fric, a.h, th, z);
+  DeferSink<M, T> sink{a.zg, k};
+  int it[2];
+  const int st = ip_step_grad<M>(a.opts, th, z, true, a.want_grad != 0, sink, it);
+#pragma unroll
+  for (int i = 0; i < nq; ++i) q3out[i] = z[M::ZQ[i]];
+  if (a.d.ok()) {
+#pragma unroll
+    for (int i = 0; i < nq; ++i) {
+      if (!a.d_skip_q2) a.d.at(i, k) = xin[nq + i];
+      a.d.at(nq + i, k) = q3out[i];
+    }
+  }
+  if (a.status.ok()) a.status.at(0, k) = st;
+  if (a.iters.ok()) { a.iters.at(0, k) = it[0]; a.iters.at(1, k) = it[1]; }
+}
+
+// independent knots (od_step, od_step_grad pass 1)
+template <class M, class T> OD_HD void unit_step_state(const StepArgs<T>& a, long b) {
   constexpr int nq = M::NQ, n = 2 * M::NQ;
-  const StepArgs<T>& a = ra.r.s;
-  T x[n], u[M::NU > 0 ? M::NU : 1];
+  T x[n], u[M::NU > 0 ? M::NU : 1], q3[nq];
 #pragma unroll
   for (int i = 0; i < n; ++i) x[i] = a.x.at(i, b);
-  if (ra.r.x0.ok()) {
 #pragma unroll
-    for (int i = 0; i < n; ++i) ra.r.x0.at(i, b) = x[i];
+  for (int i = 0; i < M::NU; ++i) u[i] = a.u.at(i, b);
+  knot_state<M, T>(a, b, x, u, q3);
+}
+
+// rollouts (od_rollout pass 1): T sequential knots per trajectory, state carried in registers.
+// Knot index of (t, b) is k = t*B + b; X has T+1 slots per trajectory, slot 0 = x1.
+template <class T> struct RolloutArgs {
+  StepArgs<T> s;     // x = x1 (2nq per trajectory); u / d / status / iters / zg are per-knot views
+  View<T> x0;        // slot 0 of X (receives a copy of x1)
+  int Tn;
+};
+
+template <class M, class T> OD_HD void unit_rollout_state(const RolloutArgs<T>& ra, long b) {
+  constexpr int nq = M::NQ, n = 2 * M::NQ;
+  const StepArgs<T>& a = ra.s;
+  T x[n], u[M::NU > 0 ? M::NU : 1], q3[nq];
+#pragma unroll
+  for (int i = 0; i < n; ++i) x[i] = a.x.at(i, b);
+  if (ra.x0.ok()) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) ra.x0.at(i, b) = x[i];
   }
-  for (int t = 0; t < ra.r.Tn; ++t) {
+  for (int t = 0; t < ra.Tn; ++t) {
     const long k = (long)t * a.B + b;
 #pragma unroll
     for (int i = 0; i < M::NU; ++i) u[i] = a.u.at(i, k);
-    T th[M::NTH], z[M::NZ];
-    mech_setup<M>(x, x + nq, u, a.fric, a.h, th, z);
-    DeferSink<M, T> sink{ra.zg, k};
-    int it[2];
-    const int st = ip_step_grad<M>(a.opts, th, z, true, a.want_grad != 0, sink, it);
+    knot_state<M, T>(a, k, x, u, q3);
 #pragma unroll
-    for (int i = 0; i < nq; ++i) { x[i] = x[nq + i]; x[nq + i] = z[M::ZQ[i]]; }
-    if (a.d.ok()) {
-#pragma unroll
-      for (int i = 0; i < n; ++i) a.d.at(i, k) = x[i];
-    }
-    if (a.status.ok()) a.status.at(0, k) = st;
-    if (a.iters.ok()) { a.iters.at(0, k) = it[0]; a.iters.at(1, k) = it[1]; }
+    for (int i = 0; i < nq; ++i) { x[i] = x[nq + i]; x[nq + i] = q3[i]; }
   }
 }
 
-// pass 2: knot k = t*B + b reads its state from X (slot k) and its control, rebuilds theta, and
-// differentiates at the recorded iterate
-template <class T> struct GradKnotArgs {
-  StepArgs<T> s;        // x = X view over (T+1)*B slots, u per knot, dx/du/dq3 outputs per knot, status per knot
-  View<const T> zg;
-  long K;               // number of knots
-};
-
-template <class M, class T> OD_HD void unit_grad_knot(const GradKnotArgs<T>& ga, long k) {
+// pass 2: knot k reads its state (a.x, slot k) and control, rebuilds theta, and differentiates at the
+// recorded iterate; writes the constant blocks of fx / fu as well ([0 I] on top, src/dynamics.jl:105-108)
+template <class M, class T> OD_HD void unit_grad_knot(const StepArgs<T>& a, long k) {
   constexpr int nq = M::NQ, n = 2 * M::NQ;
-  const StepArgs<T>& a = ga.s;
   T x[n], u[M::NU > 0 ? M::NU : 1], th[M::NTH], z[M::NZ];
 #pragma unroll
   for (int i = 0; i < n; ++i) x[i] = a.x.at(i, k);
@@ -204,8 +142,8 @@ template <class M, class T> OD_HD void unit_grad_knot(const GradKnotArgs<T>& ga,
   for (int i = 0; i < M::NU; ++i) u[i] = a.u.at(i, k);
   mech_setup<M>(x, x + nq, u, a.fric, a.h, th, z);
 #pragma unroll
-  for (int i = 0; i < M::NZ; ++i) z[i] = ga.zg.at(i, k);
-  const T reg = ga.zg.at(M::NZ, k);
+  for (int i = 0; i < M::NZ; ++i) z[i] = a.zg.at(i, k);
+  const T reg = a.zg.at(M::NZ, k);
   StepSink<M, T> sink{a, k};
   const bool ok = gradient_at<M>(th, z, reg, sink);
   if (a.dx.ok()) {

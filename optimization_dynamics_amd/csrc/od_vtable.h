@@ -6,7 +6,7 @@
 
 namespace od {
 
-struct LaunchCfg { int ppw, wpb, lds; };     // problems per wavefront, wavefronts per block (1|4), LDS factors
+struct LaunchCfg { int ppw, wpb; };     // problems per wavefront (pow2 <= 64), wavefronts per workgroup (1 | 4)
 
 struct ModelVT {
   int id, kind;
@@ -15,10 +15,9 @@ struct ModelVT {
   double r_tol, kappa_eval, kappa_grad, eps_min, kappa_reg, gamma_reg, undercut;
   int max_iter, max_ls;
   double fric_default[4];
-  hipError_t (*step)(const StepArgs<double>&, LaunchCfg, hipStream_t);          // mech models
-  hipError_t (*rollout)(const RolloutArgs<double>&, LaunchCfg, hipStream_t);    // fused single-pass rollout
-  hipError_t (*rollout_state)(const RolloutStateArgs<double>&, LaunchCfg, hipStream_t);   // split rollout, pass 1
-  hipError_t (*grad_knots)(const GradKnotArgs<double>&, hipStream_t);                     // split rollout, pass 2
+  hipError_t (*step_state)(const StepArgs<double>&, LaunchCfg, hipStream_t);        // pass 1, independent knots
+  hipError_t (*rollout_state)(const RolloutArgs<double>&, LaunchCfg, hipStream_t);  // pass 1, rollouts
+  hipError_t (*grad_knots)(const StepArgs<double>&, hipStream_t);                   // pass 2 (a.B knots)
   hipError_t (*bundle)(const BundleArgs<double>&, long, int ppw, hipStream_t);
   hipError_t (*raw64)(const RawArgs<double>&, int ppw, hipStream_t);
   hipError_t (*raw32)(const RawArgs<float>&, int ppw, hipStream_t);
@@ -44,7 +43,6 @@ constexpr int OD_BLOCK = 64;   // one wavefront per workgroup: units are indepen
 // the work over more SIMDs and shorten each wave's critical path; large batches use all 64 lanes.
 struct LaneMap {
   int ppw;                                  // problems per wavefront, power of two in [1, 64]
-  int lds;                                  // 1: KKT factors live in LDS (latency variant)
   // thread t of a block: wavefront t/64, lane t%64 (blocks are 1 or 4 wavefronts)
   __host__ __device__ long problem(unsigned block, unsigned thread, unsigned block_threads = 64) const {
     return ((long)block * (block_threads / 64) + thread / 64) * ppw + (thread & 63);

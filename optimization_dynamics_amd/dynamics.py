@@ -82,9 +82,9 @@ class ImplicitDynamics:
         if self.device.type == "cuda":
             self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def set_launch_config(self, ppw=0, split_rollout=-1):
+    def set_launch_config(self, ppw=0, waves_per_block=0):
         """launch tuning (0 / -1 = automatic), see od_set_launch_config"""
-        self.lib.check(self.lib.cdll.od_set_launch_config(self._h, int(ppw), int(split_rollout)))
+        self.lib.check(self.lib.cdll.od_set_launch_config(self._h, int(ppw), int(waves_per_block)))
 
     def synchronize(self):
         self.lib.check(self.lib.cdll.od_synchronize(self._h))
