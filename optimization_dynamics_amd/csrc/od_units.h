@@ -9,11 +9,29 @@ namespace od {
 // strided view: element e of problem b lives at p[e*se + b*sb]
 //   batch-minor SoA (coalesced across lanes): se = batch capacity, sb = 1
 //   batch-major  (Julia n x B matrix)       : se = 1, sb = elements per problem
+#if defined(__HIP_DEVICE_COMPILE__)
+// keeps the compiler from rewriting a running pointer as base + e*stride with one hoisted scalar
+// offset per element: those offsets (dozens per view) otherwise live in SGPRs across the whole
+// interior-point loop and are spilled to VGPR lanes (v_writelane/v_readlane)
+#define OD_OPAQUE_PTR(p) asm volatile("" : "+v"(p))
+#else
+#define OD_OPAQUE_PTR(p) (void)0
+#endif
+
 template <class T> struct View {
   T* p;
   long se, sb;
   OD_HD T& at(long e, long b) const { return p[e * se + b * sb]; }
   OD_HD bool ok() const { return p != nullptr; }
+  // sequential access to elements 0, 1, 2, ... of problem b
+  struct Cursor {
+    T* q;
+    long se;
+    OD_HD void put(T v) { *q = v; q += se; OD_OPAQUE_PTR(q); }
+    OD_HD T get() { const T v = *q; q += se; OD_OPAQUE_PTR(q); return v; }
+    OD_HD void skip(int n) { q += n * se; OD_OPAQUE_PTR(q); }
+  };
+  OD_HD Cursor cursor(long b) const { Cursor c{p + b * sb, se}; OD_OPAQUE_PTR(c.q); return c; }
 };
 
 // ---- f / fx / fu (src/dynamics.jl:81-128) ------------------------------------------------------
@@ -64,9 +82,10 @@ template <class M, class T> struct DeferSink {
   long k;
   OD_HD void grad(int, int, T) {}
   OD_HD void defer(const T* z, T reg) {
+    auto c = zg.cursor(k);
 #pragma unroll
-    for (int i = 0; i < M::NZ; ++i) zg.at(i, k) = z[i];
-    zg.at(M::NZ, k) = reg;
+    for (int i = 0; i < M::NZ; ++i) c.put(z[i]);
+    c.put(reg);
   }
 };
 
@@ -82,14 +101,17 @@ OD_HD void knot_state(const StepArgs<T>& a, long k, const T* xin, const T* uin, 
 #pragma unroll
   for (int i = 0; i < nq; ++i) q3out[i] = z[M::ZQ[i]];
   if (a.d.ok()) {
+    auto c = a.d.cursor(k);
+    if (a.d_skip_q2) c.skip(nq);
+    else {
 #pragma unroll
-    for (int i = 0; i < nq; ++i) {
-      if (!a.d_skip_q2) a.d.at(i, k) = xin[nq + i];
-      a.d.at(nq + i, k) = q3out[i];
+      for (int i = 0; i < nq; ++i) c.put(xin[nq + i]);
     }
+#pragma unroll
+    for (int i = 0; i < nq; ++i) c.put(q3out[i]);
   }
   if (a.status.ok()) a.status.at(0, k) = st;
-  if (a.iters.ok()) { a.iters.at(0, k) = it[0]; a.iters.at(1, k) = it[1]; }
+  if (a.iters.ok()) { auto c = a.iters.cursor(k); c.put(it[0]); c.put(it[1]); }
 }
 
 // independent knots (od_step, od_step_grad pass 1)
@@ -123,8 +145,11 @@ template <class M, class T> OD_HD void unit_rollout_state(const RolloutArgs<T>& 
   }
   for (int t = 0; t < ra.Tn; ++t) {
     const long k = (long)t * a.B + b;
+    {
+      auto c = a.u.cursor(k);
 #pragma unroll
-    for (int i = 0; i < M::NU; ++i) u[i] = a.u.at(i, k);
+      for (int i = 0; i < M::NU; ++i) u[i] = c.get();
+    }
     knot_state<M, T>(a, k, x, u, q3);
 #pragma unroll
     for (int i = 0; i < nq; ++i) { x[i] = x[nq + i]; x[nq + i] = q3[i]; }

@@ -1,0 +1,29 @@
+"""Throughput of the other BASELINE.json configs on one MI355X (not the contract bench)."""
+import sys, time, json
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np, torch
+import workloads as W, parity_checks as P
+import optimization_dynamics_amd as od
+lib = od.default_library()
+dev = 'cuda:0'
+out = {}
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.time() - t0) / n
+for name, B in [('acrobot_impact', 1024), ('acrobot_impact', 262144), ('hopper', 4096), ('hopper', 262144), ('cartpole_friction', 262144), ('planar_push', 65536)]:
+    X, U = W.knots(name, B, seed=1)
+    im = P.make_im(name, lib, dev); Xd, Ud = torch.tensor(X, device=dev), torch.tensor(U, device=dev)
+    dt = timeit(lambda: im.step_grad(Xd, Ud))
+    out['step_grad %s B=%d' % (name, B)] = dict(ms=round(dt * 1e3, 3), units_per_s=B / dt)
+gb = od.GradientBundle(od.planarpush, N=256, eps=1e-4, seed=0)
+im = P.make_im('planar_push', lib, dev)
+X, U = W.knots('planar_push', 50, seed=2); Xd, Ud = torch.tensor(X, device=dev), torch.tensor(U, device=dev)
+dt = timeit(lambda: od.gradient_batch(im, gb, Xd, Ud))
+out['bundle planar_push N=256 x 50 knots'] = dict(ms=round(dt * 1e3, 3), solves_per_s=50 * 257 / dt)
+for dtype in (torch.float64, torch.float32):
+    info = od.RocketInfo(od.rocket, 12.5, 0.05, dtype=dtype, device=dev)
+    X, U = W.rocket_inputs(65536, seed=3); Xd, Ud = torch.tensor(X, device=dev), torch.tensor(U, device=dev)
+    dt = timeit(lambda: info.solve(Xd, Ud, project=True, grads=True))
+    out['rocket_proj f+fx+fu %s B=65536' % str(dtype)] = dict(ms=round(dt * 1e3, 3), units_per_s=65536 / dt)
+print(json.dumps(out, indent=1))
