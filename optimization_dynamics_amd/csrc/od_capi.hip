@@ -69,27 +69,41 @@ template <class T> Opts<T> to_opts(const od_options& o) {
 //   sum_i | f_eta_i - f_z - M eta_i |^2 ,   M = ny x nzb,
 // in closed form (normal equations M * sum(eta eta') = sum((f_eta - f_z) eta')): the cost is exactly
 // quadratic, so the reference's Newton iteration lands on this minimiser in one step.
-// One lane per knot; sizes are runtime (tiny kernel, B = number of knots).
+// Two kernels: (1) one lane per entry of [G | R'] = [sum eta eta' | sum eta (f_eta - f_z)'] per fit
+// (N-term dot products, B * nzb * (nzb + ny) lanes), (2) one lane per fit: LU with partial pivoting
+// (RoboDojo lu_solver, src/ls.jl:52) and ny back-solves.  ne = nzb * (nzb + ny) doubles of scratch per fit.
 constexpr int OD_LS_MAX = 24;
-__global__ __launch_bounds__(OD_BLOCK) void k_lsfit(long B, int N, int ny, int nzb, const double* eta,
-                                                   View<const double> feta, View<double> dz, View<int> status) {
+__global__ __launch_bounds__(OD_BLOCK) void k_ls_accumulate(long B, int N, int ny, int nzb, const double* eta,
+                                                           View<const double> feta, double* acc) {
+  const int ne = nzb * (nzb + ny);
+  const long t = (long)blockIdx.x * OD_BLOCK + threadIdx.x;
+  if (t >= B * ne) return;
+  const long b = t / ne;
+  const int e = (int)(t - b * ne);
+  const int r = e % nzb, c = e / nzb;          // column-major nzb x (nzb + ny)
+  const long p0 = b * (N + 1);
+  double s = 0.0;
+  if (c < nzb) {
+    for (int i = 0; i < N; ++i) s += eta[r + (long)nzb * i] * eta[c + (long)nzb * i];
+  } else {
+    const int a = c - nzb;
+    const double fz = feta.at(a, p0);
+    for (int i = 0; i < N; ++i) s += eta[r + (long)nzb * i] * (feta.at(a, p0 + 1 + i) - fz);
+  }
+  acc[t] = s;
+}
+
+__global__ __launch_bounds__(OD_BLOCK) void k_ls_solve(long B, int ny, int nzb, const double* acc,
+                                                      View<double> dz, View<int> status) {
   const long b = (long)blockIdx.x * OD_BLOCK + threadIdx.x;
   if (b >= B) return;
-  double A[OD_LS_MAX * OD_LS_MAX], R[OD_LS_MAX * OD_LS_MAX], fz[OD_LS_MAX], x[OD_LS_MAX];
+  const int ne = nzb * (nzb + ny);
+  double A[OD_LS_MAX * OD_LS_MAX], x[OD_LS_MAX];
   int piv[OD_LS_MAX];
-  for (int i = 0; i < nzb * nzb; ++i) A[i] = 0.0;
-  for (int i = 0; i < ny * nzb; ++i) R[i] = 0.0;
-  const long p0 = b * (N + 1);
-  for (int a = 0; a < ny; ++a) fz[a] = feta.at(a, p0);
-  for (int i = 0; i < N; ++i) {
-    const double* e = eta + (long)nzb * i;
-    for (int c = 0; c < nzb; ++c)
-      for (int r = 0; r < nzb; ++r) A[r + nzb * c] += e[r] * e[c];
-    for (int c = 0; c < nzb; ++c)
-      for (int a = 0; a < ny; ++a) R[a + ny * c] += (feta.at(a, p0 + 1 + i) - fz[a]) * e[c];
-  }
+  const double* g = acc + b * ne;
+  for (int i = 0; i < nzb * nzb; ++i) A[i] = g[i];
   bool ok = true;
-  for (int k = 0; k < nzb; ++k) {   // LU with partial pivoting (RoboDojo lu_solver, src/ls.jl:52)
+  for (int k = 0; k < nzb; ++k) {
     int p = k;
     double best = fabs(A[k + nzb * k]);
     for (int i = k + 1; i < nzb; ++i) { const double v = fabs(A[i + nzb * k]); if (v > best) { best = v; p = i; } }
@@ -100,8 +114,8 @@ __global__ __launch_bounds__(OD_BLOCK) void k_lsfit(long B, int N, int ny, int n
     for (int i = k + 1; i < nzb; ++i) A[i + nzb * k] *= inv;
     for (int j = k + 1; j < nzb; ++j) { const double ukj = A[k + nzb * j]; for (int i = k + 1; i < nzb; ++i) A[i + nzb * j] -= A[i + nzb * k] * ukj; }
   }
-  for (int a = 0; a < ny; ++a) {
-    for (int c = 0; c < nzb; ++c) x[c] = R[a + ny * c];
+  for (int a = 0; a < ny; ++a) {               // G symmetric: row a of M solves G x = R(a,:)'
+    for (int c = 0; c < nzb; ++c) x[c] = g[nzb * nzb + c + nzb * a];
     for (int k = 0; k < nzb; ++k) { const int p = piv[k]; if (p != k) { const double t = x[k]; x[k] = x[p]; x[p] = t; } }
     for (int k = 0; k < nzb; ++k) for (int i = k + 1; i < nzb; ++i) x[i] -= A[i + nzb * k] * x[k];
     for (int k = nzb - 1; k >= 0; --k) { x[k] /= A[k + nzb * k]; for (int i = 0; i < k; ++i) x[i] -= A[i + nzb * k] * x[k]; }
@@ -445,7 +459,19 @@ int od_rollout(od_handle h, long B, int T, const void* x1, const void* U, void* 
 
 size_t od_bundle_workspace_bytes(od_handle h, long B, int N) {
   if (!h || B <= 0 || N <= 0) return 0;
-  return sizeof(double) * (size_t)h->vt->nq * (size_t)(N + 1) * (size_t)B + sizeof(int) * (size_t)(N + 1) * (size_t)B;
+  const size_t nq = h->vt->nq, nzb = 2 * nq + h->vt->nu;
+  return sizeof(double) * (nq * (size_t)(N + 1) * (size_t)B + nzb * (nzb + nq) * (size_t)B) + sizeof(int) * (size_t)(N + 1) * (size_t)B;
+}
+
+static int run_ls(od_handle h, long B, int N, int ny, int nzb, const double* eta, View<const double> fv, double* acc,
+                  void* M, int* status) {
+  const long ne = (long)nzb * (nzb + ny);
+  hipLaunchKernelGGL(k_ls_accumulate, od_grid(B * ne, OD_BLOCK), dim3(OD_BLOCK), 0, h->stream, B, N, ny, nzb, eta, fv, acc);
+  OD_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_ls_solve, od_grid(B, OD_BLOCK), dim3(OD_BLOCK), 0, h->stream, B, ny, nzb, (const double*)acc,
+                     mkview<double>(M, ny * nzb, B, h->layout), mkview<int>(status, 1, B, h->layout));
+  OD_HIP(hipGetLastError());
+  return OD_OK;
 }
 
 int od_bundle_grad(od_handle h, long B, int N, const void* x, const void* u, const void* eta, void* dz,
@@ -461,14 +487,14 @@ int od_bundle_grad(od_handle h, long B, int N, const void* x, const void* u, con
   a.N = N;
   a.eta = (const double*)eta;
   a.feta = mkview<double>(ws, nq, P, OD_LAYOUT_BATCH_MINOR);
-  a.status = mkview<int>((char*)ws + sizeof(double) * (size_t)nq * P, 1, P, OD_LAYOUT_BATCH_MINOR);
-  OD_HIP(h->vt->bundle(a, P, ppw_of(h, P), h->stream));
+  a.status = mkview<int>(nullptr, 1, P, OD_LAYOUT_BATCH_MINOR);
   View<const double> fv;
   fv.p = a.feta.p; fv.se = a.feta.se; fv.sb = a.feta.sb;
-  hipLaunchKernelGGL(k_lsfit, od_grid(B, OD_BLOCK), dim3(OD_BLOCK), 0, h->stream, B, N, nq, nzb, (const double*)eta, fv,
-                     mkview<double>(dz, nq * nzb, B, h->layout), mkview<int>(status, 1, B, h->layout));
-  OD_HIP(hipGetLastError());
-  return OD_OK;
+  // workspace layout: feta (nq*P doubles) | normal-equation entries (nzb*(nzb+nq)*B doubles) | sample status (P ints)
+  double* acc = (double*)ws + (size_t)nq * P;
+  a.status.p = (int*)(acc + (size_t)nzb * (nzb + nq) * B);
+  OD_HIP(h->vt->bundle(a, P, ppw_of(h, P), h->stream));
+  return run_ls(h, B, N, nq, nzb, (const double*)eta, fv, acc, dz, status);
 }
 
 int od_ls_fit(od_handle h, long B, int N, int ny, int nzb, const void* eta, const void* feta, void* M, int* status) {
@@ -477,10 +503,8 @@ int od_ls_fit(od_handle h, long B, int N, int ny, int nzb, const void* eta, cons
   if (N <= 0 || ny <= 0 || nzb <= 0 || ny > OD_LS_MAX || nzb > OD_LS_MAX || !eta || !feta || !M)
     return fail(OD_ERR_INVALID, "od_ls_fit: bad arguments (ny, nzb <= 24)");
   View<const double> fv = mkcview<double>(feta, ny, (long)(N + 1) * B, OD_LAYOUT_BATCH_MINOR);
-  hipLaunchKernelGGL(k_lsfit, od_grid(B, OD_BLOCK), dim3(OD_BLOCK), 0, h->stream, B, N, ny, nzb, (const double*)eta, fv,
-                     mkview<double>(M, ny * nzb, B, h->layout), mkview<int>(status, 1, B, h->layout));
-  OD_HIP(hipGetLastError());
-  return OD_OK;
+  if (int rc = ensure_work(h, (size_t)nzb * (nzb + ny) * (size_t)B)) return rc;
+  return run_ls(h, B, N, ny, nzb, (const double*)eta, fv, h->work, M, status);
 }
 
 int od_ip_solve(od_handle h, long B, const void* z0, const void* theta, void* z, void* dz, int* status, int* iters) {
