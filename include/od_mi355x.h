@@ -109,6 +109,23 @@ int od_step_grad_compact(od_handle h, long B, const void* x, const void* u, void
 int od_rollout(od_handle h, long B, int T, const void* x1, const void* U, void* X, void* A, void* Bm,
                int* status, int* iters);
 
+/* ---- next row of the scope table: the iLQR iteration around the path -----------------
+ * Forward pass / Armijo line search of IterativeLQR (iLQR.solve!, examples/acrobot.jl:113): closed-loop
+ * rollouts u_t = ubar_t + alpha k_t + K_t (x_t - xbar_t) of B nominal trajectories for nalpha step sizes
+ * at once (candidate p = a*B + b).  alphas: nalpha doubles (device); x1: 2nq per nominal trajectory;
+ * xbar: 2nq per slot ((T+1)*B); ubar, kff: nu per nominal knot; K: nu x 2nq col-major per nominal knot;
+ * X: 2nq per slot ((T+1)*B*nalpha), U: nu per candidate knot (T*B*nalpha).  State only (no gradients). */
+int od_rollout_policy(od_handle h, long B, int T, int nalpha, const void* alphas, const void* x1, const void* xbar,
+                      const void* ubar, const void* K, const void* kff, void* X, void* U, int* status, int* iters);
+
+/* Riccati backward pass (Gauss-Newton iLQR) for B trajectories with a per-knot quadratic cost model:
+ * A (n x n), Bm (n x m) from od_rollout; lxx (n x n), luu (m x m), lux (m x n), lx (n), lu (m) per knot;
+ * VxxT (n x n), VxT (n) per trajectory; reg added to the diagonal of Quu.  Outputs K (m x n), k (m) per knot,
+ * dV = [sum k'Qu, sum 1/2 k'Quu k] per trajectory, status 1 = all Quu positive definite.  n <= 16, m <= 12. */
+int od_ilqr_backward(od_handle h, long B, int T, int n, int m, const void* A, const void* Bm, const void* lxx,
+                     const void* luu, const void* lux, const void* lx, const void* lu, const void* VxxT,
+                     const void* VxT, double reg, void* K, void* k, void* dV, int* status);
+
 /* gradient! (src/gradient_bundle.jl:87-104) for B knots: N+1 eval-simulator steps per knot with the
  * caller's perturbations eta ((2nq+nu) x N col-major, shared by all knots; the reference draws them
  * in the GradientBundle constructor :49-54) followed by the least-squares fit of src/ls.jl:44-60.

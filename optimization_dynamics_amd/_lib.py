@@ -56,6 +56,8 @@ SIGNATURES = {
     "od_step_grad": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _VP, _VP, _IP, _IP]),
     "od_step_grad_compact": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _VP, _IP, _IP]),
     "od_rollout": (C.c_int, [_VP, C.c_long, C.c_int, _VP, _VP, _VP, _VP, _VP, _IP, _IP]),
+    "od_rollout_policy": (C.c_int, [_VP, C.c_long, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _IP, _IP]),
+    "od_ilqr_backward": (C.c_int, [_VP, C.c_long, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_double, _VP, _VP, _VP, _IP]),
     "od_bundle_workspace_bytes": (C.c_size_t, [_VP, C.c_long, C.c_int]),
     "od_bundle_grad": (C.c_int, [_VP, C.c_long, C.c_int, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _IP]),
     "od_ls_fit": (C.c_int, [_VP, C.c_long, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _IP]),

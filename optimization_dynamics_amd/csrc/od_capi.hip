@@ -124,6 +124,89 @@ __global__ __launch_bounds__(OD_BLOCK) void k_ls_solve(long B, int ny, int nzb, 
   if (status.ok()) status.at(0, b) = ok ? 1 : 0;
 }
 
+
+// ---- iLQR backward pass (Riccati recursion), one lane per trajectory; runtime sizes n <= 16, m <= 12 --------
+// Gauss-Newton iLQR with the quadratic cost model supplied per knot (IterativeLQR's backward pass as recalled,
+// SURVEY.md Appendix A; first-order dynamics only):
+//   Qx = lx + A'Vx, Qu = lu + B'Vx, Qxx = lxx + A'Vxx A, Quu = luu + B'Vxx B + reg I, Qux = lux + B'Vxx A
+//   K = -Quu^{-1} Qux, k = -Quu^{-1} Qu, Vx = Qx + K'Quu k + K'Qu + Qux'k, Vxx = Qxx + K'Quu K + K'Qux + Qux'K
+constexpr int OD_IL_N = 16, OD_IL_M = 12;
+struct IlqrArgs {
+  long B; int T, n, m; double reg;
+  View<const double> A, Bm, lxx, luu, lux, lx, lu;   // per knot (T*B)
+  View<const double> VxxT, VxT;                      // per trajectory
+  View<double> K, k;                                 // per knot: m x n col-major, m
+  View<double> dV;                                   // per trajectory: [sum k'Qu, sum 0.5 k'Quu k]
+  View<int> status;                                  // per trajectory: 1 = every Quu factorised (positive pivots)
+};
+__global__ __launch_bounds__(OD_BLOCK) void k_ilqr_backward(IlqrArgs a) {
+  const long b = (long)blockIdx.x * OD_BLOCK + threadIdx.x;
+  if (b >= a.B) return;
+  const int n = a.n, m = a.m;
+  double Vxx[OD_IL_N * OD_IL_N], Vx[OD_IL_N], At[OD_IL_N * OD_IL_N], Bt[OD_IL_N * OD_IL_M], W[OD_IL_N * OD_IL_N];
+  double Qxx[OD_IL_N * OD_IL_N], Quu[OD_IL_M * OD_IL_M], Qux[OD_IL_M * OD_IL_N], Qx[OD_IL_N], Qu[OD_IL_M];
+  double L[OD_IL_M * OD_IL_M], Kt[OD_IL_M * OD_IL_N], kt[OD_IL_M];
+  for (int i = 0; i < n * n; ++i) Vxx[i] = a.VxxT.at(i, b);
+  for (int i = 0; i < n; ++i) Vx[i] = a.VxT.at(i, b);
+  double dV1 = 0.0, dV2 = 0.0;
+  bool ok = true;
+  for (int t = a.T - 1; t >= 0; --t) {
+    const long kk = (long)t * a.B + b;
+    for (int i = 0; i < n * n; ++i) At[i] = a.A.at(i, kk);
+    for (int i = 0; i < n * m; ++i) Bt[i] = a.Bm.at(i, kk);
+    // W = Vxx * A  (n x n)
+    for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) { double s = 0; for (int l = 0; l < n; ++l) s += Vxx[i + n * l] * At[l + n * j]; W[i + n * j] = s; }
+    for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) { double s = a.lxx.at(i + n * j, kk); for (int l = 0; l < n; ++l) s += At[l + n * i] * W[l + n * j]; Qxx[i + n * j] = s; }
+    for (int j = 0; j < n; ++j) for (int i = 0; i < m; ++i) { double s = a.lux.at(i + m * j, kk); for (int l = 0; l < n; ++l) s += Bt[l + n * i] * W[l + n * j]; Qux[i + m * j] = s; }
+    // W(:, 0:m) = Vxx * B
+    for (int j = 0; j < m; ++j) for (int i = 0; i < n; ++i) { double s = 0; for (int l = 0; l < n; ++l) s += Vxx[i + n * l] * Bt[l + n * j]; W[i + n * j] = s; }
+    for (int j = 0; j < m; ++j) for (int i = 0; i < m; ++i) { double s = a.luu.at(i + m * j, kk); for (int l = 0; l < n; ++l) s += Bt[l + n * i] * W[l + n * j]; Quu[i + m * j] = s; }
+    for (int i = 0; i < n; ++i) { double s = a.lx.at(i, kk); for (int l = 0; l < n; ++l) s += At[l + n * i] * Vx[l]; Qx[i] = s; }
+    for (int i = 0; i < m; ++i) { double s = a.lu.at(i, kk); for (int l = 0; l < n; ++l) s += Bt[l + n * i] * Vx[l]; Qu[i] = s; }
+    // Cholesky of Quu + reg I
+    for (int i = 0; i < m * m; ++i) L[i] = Quu[i];
+    for (int i = 0; i < m; ++i) L[i + m * i] += a.reg;
+    for (int j = 0; j < m; ++j) {
+      double d = L[j + m * j];
+      for (int l = 0; l < j; ++l) d -= L[j + m * l] * L[j + m * l];
+      if (!(d > 0.0)) { ok = false; d = 1e-12; }
+      d = sqrt(d);
+      L[j + m * j] = d;
+      for (int i = j + 1; i < m; ++i) { double s = L[i + m * j]; for (int l = 0; l < j; ++l) s -= L[i + m * l] * L[j + m * l]; L[i + m * j] = s / d; }
+    }
+    // K = -(Quu+reg)^{-1} Qux (column by column), k = -(Quu+reg)^{-1} Qu
+    for (int c = 0; c <= n; ++c) {
+      double y[OD_IL_M];
+      for (int i = 0; i < m; ++i) y[i] = (c < n) ? Qux[i + m * c] : Qu[i];
+      for (int i = 0; i < m; ++i) { double s = y[i]; for (int l = 0; l < i; ++l) s -= L[i + m * l] * y[l]; y[i] = s / L[i + m * i]; }
+      for (int i = m - 1; i >= 0; --i) { double s = y[i]; for (int l = i + 1; l < m; ++l) s -= L[l + m * i] * y[l]; y[i] = s / L[i + m * i]; }
+      for (int i = 0; i < m; ++i) { if (c < n) Kt[i + m * c] = -y[i]; else kt[i] = -y[i]; }
+    }
+    for (int i = 0; i < m * n; ++i) a.K.at(i, kk) = Kt[i];
+    for (int i = 0; i < m; ++i) a.k.at(i, kk) = kt[i];
+    for (int i = 0; i < m; ++i) { dV1 += kt[i] * Qu[i]; double s = 0; for (int l = 0; l < m; ++l) s += Quu[i + m * l] * kt[l]; dV2 += 0.5 * kt[i] * s; }
+    // value function update (Quu without reg, as in the cost-to-go expansion)
+    double Quuk[OD_IL_M];
+    for (int i = 0; i < m; ++i) { double s = 0; for (int l = 0; l < m; ++l) s += Quu[i + m * l] * kt[l]; Quuk[i] = s; }
+    for (int i = 0; i < n; ++i) {
+      double s = Qx[i];
+      for (int l = 0; l < m; ++l) s += Kt[l + m * i] * (Quuk[l] + Qu[l]) + Qux[l + m * i] * kt[l];
+      Vx[i] = s;
+    }
+    // W(m x n) = Quu * K
+    for (int j = 0; j < n; ++j) for (int i = 0; i < m; ++i) { double s = 0; for (int l = 0; l < m; ++l) s += Quu[i + m * l] * Kt[l + m * j]; W[i + m * j] = s; }
+    for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) {
+      double s = Qxx[i + n * j];
+      for (int l = 0; l < m; ++l) s += Kt[l + m * i] * (W[l + m * j] + Qux[l + m * j]) + Qux[l + m * i] * Kt[l + m * j];
+      Vxx[i + n * j] = s;
+    }
+    for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) { const double s = 0.5 * (Vxx[i + n * j] + Vxx[j + n * i]); Vxx[i + n * j] = s; Vxx[j + n * i] = s; }
+  }
+  a.dV.at(0, b) = dV1;
+  a.dV.at(1, b) = dV2;
+  if (a.status.ok()) a.status.at(0, b) = ok ? 1 : 0;
+}
+
 }  // namespace
 
 struct od_handle_s {
@@ -455,6 +538,56 @@ int od_rollout(od_handle h, long B, int T, const void* x1, const void* U, void* 
   View<const double> xin;
   xin.p = xv.p; xin.se = xv.se; xin.sb = xv.sb;                        // state of knot k = slot k of X
   return run_grad_pass(h, r.s, K, xin);                                // pass 2: all T*B gradients
+}
+
+int od_rollout_policy(od_handle h, long B, int T, int nalpha, const void* alphas, const void* x1, const void* xbar,
+                      const void* ubar, const void* K, const void* kff, void* X, void* U, int* status, int* iters) {
+  if (int rc = check_mech(h, "od_rollout_policy")) return rc;
+  if (B <= 0 || T <= 0 || nalpha <= 0) return OD_OK;
+  if (!alphas || !x1 || !xbar || !ubar || !K || !kff || !X || !U) return fail(OD_ERR_INVALID, "od_rollout_policy: null argument");
+  const int n = 2 * h->vt->nq, nu = h->vt->nu, L = h->layout;
+  const long P = B * nalpha, Kn = (long)T * B, Kc = (long)T * P;
+  PolicyArgs<double> pa;
+  pa.r.s = step_args(h, P, Kc, x1, nullptr, nullptr, nullptr, nullptr, nullptr, status, iters, 0);
+  pa.r.s.x = mkcview<double>(x1, n, B, L);
+  View<double> xv = mkview<double>(X, n, (long)(T + 1) * P, L);
+  pa.r.x0 = xv;
+  pa.r.s.d = xv;
+  pa.r.s.d.p += (long)P * xv.sb;
+  pa.r.Tn = T;
+  pa.Bnom = B;
+  pa.nalpha = nalpha;
+  pa.alphas = (const double*)alphas;
+  pa.xbar = mkcview<double>(xbar, n, (long)(T + 1) * B, L);
+  pa.ubar = mkcview<double>(ubar, nu, Kn, L);
+  pa.K = mkcview<double>(K, nu * n, Kn, L);
+  pa.kff = mkcview<double>(kff, nu, Kn, L);
+  pa.U = mkview<double>(U, nu, Kc, L);
+  OD_HIP(h->vt->rollout_policy(pa, cfg_of(h, P), h->stream));
+  return OD_OK;
+}
+
+int od_ilqr_backward(od_handle h, long B, int T, int n, int m, const void* A, const void* Bm, const void* lxx,
+                     const void* luu, const void* lux, const void* lx, const void* lu, const void* VxxT,
+                     const void* VxT, double reg, void* K, void* k, void* dV, int* status) {
+  if (!h) return fail(OD_ERR_INVALID, "od_ilqr_backward: null handle");
+  if (B <= 0 || T <= 0) return OD_OK;
+  if (n <= 0 || m <= 0 || n > OD_IL_N || m > OD_IL_M) return fail(OD_ERR_INVALID, "od_ilqr_backward: n <= 16, m <= 12");
+  if (!A || !Bm || !lxx || !luu || !lux || !lx || !lu || !VxxT || !VxT || !K || !k || !dV)
+    return fail(OD_ERR_INVALID, "od_ilqr_backward: null argument");
+  const int L = h->layout;
+  const long Kn = (long)T * B;
+  IlqrArgs a;
+  a.B = B; a.T = T; a.n = n; a.m = m; a.reg = reg;
+  a.A = mkcview<double>(A, n * n, Kn, L); a.Bm = mkcview<double>(Bm, n * m, Kn, L);
+  a.lxx = mkcview<double>(lxx, n * n, Kn, L); a.luu = mkcview<double>(luu, m * m, Kn, L);
+  a.lux = mkcview<double>(lux, m * n, Kn, L); a.lx = mkcview<double>(lx, n, Kn, L); a.lu = mkcview<double>(lu, m, Kn, L);
+  a.VxxT = mkcview<double>(VxxT, n * n, B, L); a.VxT = mkcview<double>(VxT, n, B, L);
+  a.K = mkview<double>(K, m * n, Kn, L); a.k = mkview<double>(k, m, Kn, L);
+  a.dV = mkview<double>(dV, 2, B, L); a.status = mkview<int>(status, 1, B, L);
+  hipLaunchKernelGGL(k_ilqr_backward, od_grid(B, OD_BLOCK), dim3(OD_BLOCK), 0, h->stream, a);
+  OD_HIP(hipGetLastError());
+  return OD_OK;
 }
 
 size_t od_bundle_workspace_bytes(od_handle h, long B, int N) {

@@ -156,6 +156,63 @@ template <class M, class T> OD_HD void unit_rollout_state(const RolloutArgs<T>& 
   }
 }
 
+// ---- closed-loop rollout = forward pass of iLQR (examples/*.jl: iLQR.solve! line search) ----
+// Candidate trajectory p = a*Bnom + b follows nominal trajectory b with step size alphas[a]:
+//   u_t = ubar_t + alpha * k_t + K_t (x_t - xbar_t).
+// All step sizes of the Armijo line search are rolled out speculatively in one launch.
+template <class T> struct PolicyArgs {
+  RolloutArgs<T> r;      // r.s.B = P = Bnom*nalpha candidates; r.s.x = x1 of the Bnom nominal trajectories
+  long Bnom;
+  int nalpha;
+  const T* alphas;
+  View<const T> xbar;    // 2nq per slot, (T+1)*Bnom slots
+  View<const T> ubar;    // nu per nominal knot
+  View<const T> K;       // nu x 2nq col-major per nominal knot
+  View<const T> kff;     // nu per nominal knot
+  View<T> U;             // nu per candidate knot: controls actually applied
+};
+
+template <class M, class T> OD_HD void unit_rollout_policy(const PolicyArgs<T>& pa, long p) {
+  constexpr int nq = M::NQ, n = 2 * M::NQ, nu = M::NU > 0 ? M::NU : 1;
+  const StepArgs<T>& a = pa.r.s;
+  const long b = p % pa.Bnom;
+  const T alpha = pa.alphas[p / pa.Bnom];
+  T x[n], u[nu], q3[nq];
+#pragma unroll
+  for (int i = 0; i < n; ++i) x[i] = a.x.at(i, b);
+  if (pa.r.x0.ok()) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) pa.r.x0.at(i, p) = x[i];
+  }
+  for (int t = 0; t < pa.r.Tn; ++t) {
+    const long kn = (long)t * pa.Bnom + b, kc = (long)t * a.B + p;
+    T dx[n];
+    {
+      auto c = pa.xbar.cursor(kn);
+#pragma unroll
+      for (int i = 0; i < n; ++i) dx[i] = x[i] - c.get();
+    }
+    {
+      auto cu = pa.ubar.cursor(kn);
+      auto ck = pa.kff.cursor(kn);
+      auto cK = pa.K.cursor(kn);
+#pragma unroll
+      for (int j = 0; j < M::NU; ++j) u[j] = cu.get() + alpha * ck.get();
+#pragma unroll
+      for (int i = 0; i < n; ++i) {            // K is nu x n col-major: column i multiplies dx[i]
+#pragma unroll
+        for (int j = 0; j < M::NU; ++j) u[j] += cK.get() * dx[i];
+      }
+      auto co = pa.U.cursor(kc);
+#pragma unroll
+      for (int j = 0; j < M::NU; ++j) co.put(u[j]);
+    }
+    knot_state<M, T>(a, kc, x, u, q3);
+#pragma unroll
+    for (int i = 0; i < nq; ++i) { x[i] = x[nq + i]; x[nq + i] = q3[i]; }
+  }
+}
+
 // pass 2: knot k reads its state (a.x, slot k) and control, rebuilds theta, and differentiates at the
 // recorded iterate; writes the constant blocks of fx / fu as well ([0 I] on top, src/dynamics.jl:105-108)
 template <class M, class T> OD_HD void unit_grad_knot(const StepArgs<T>& a, long k) {

@@ -18,6 +18,7 @@ struct ModelVT {
   hipError_t (*step_state)(const StepArgs<double>&, LaunchCfg, hipStream_t);        // pass 1, independent knots
   hipError_t (*rollout_state)(const RolloutArgs<double>&, LaunchCfg, hipStream_t);  // pass 1, rollouts
   hipError_t (*grad_knots)(const StepArgs<double>&, hipStream_t);                   // pass 2 (a.B knots)
+  hipError_t (*rollout_policy)(const PolicyArgs<double>&, LaunchCfg, hipStream_t);  // closed-loop rollouts
   hipError_t (*bundle)(const BundleArgs<double>&, long, int ppw, hipStream_t);
   hipError_t (*raw64)(const RawArgs<double>&, int ppw, hipStream_t);
   hipError_t (*raw32)(const RawArgs<float>&, int ppw, hipStream_t);

@@ -1,0 +1,165 @@
+"""Batched iLQR around the implicit dynamics -- the consumer of the path.
+
+The reference hands its `f / fx / fu` callbacks to IterativeLQR.jl (un-vendored; interface visible at
+examples/acrobot.jl:33-36,97-113): an augmented-Lagrangian outer loop around iLQR iterations made of
+(1) a derivative sweep, (2) a Riccati backward pass, (3) a forward pass with Armijo backtracking.
+Here B independent trajectory optimisations run at once:
+
+    (1) `od_rollout`          nominal rollout + linearisation (x+, A, B) of every knot
+    (2) `od_ilqr_backward`    Riccati recursion, one lane per trajectory
+    (3) `od_rollout_policy`   ALL Armijo step sizes of all trajectories rolled out speculatively in one launch
+
+Costs are quadratic (what the reference's examples use for tracking / effort terms), terminal equality
+constraints x_T[idx] = goal are handled by the augmented Lagrangian like the reference's `terminal_con`.
+Internals of IterativeLQR are recalled, not pinned (same status as the solver).
+"""
+import numpy as np
+import torch
+
+from .dynamics import ImplicitDynamics, _ptr
+
+
+class QuadraticObjective:
+    """sum_t 1/2 (x_t - x_ref)'Q(x_t - x_ref) + 1/2 u_t'R u_t  +  1/2 (x_T - x_ref)'QT(x_T - x_ref)
+    (cf. objt / objT of examples/hopper.jl:207-220), plus an AL term for  x_T[idx] = goal."""
+
+    def __init__(self, Q, R, QT, x_ref, goal_idx=None, goal=None, device="cuda"):
+        dev = torch.device(device)
+        as_t = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64), device=dev)
+        self.Q, self.R, self.QT, self.x_ref = as_t(Q), as_t(R), as_t(QT), as_t(x_ref)
+        self.n, self.m = self.Q.shape[0], self.R.shape[0]
+        self.goal_idx = None if goal_idx is None else torch.as_tensor(np.asarray(goal_idx), device=dev, dtype=torch.long)
+        self.goal = None if goal is None else as_t(goal)
+        self.device = dev
+
+    def constraint(self, X):
+        """c = x_T[idx] - goal, shape (nc, P)"""
+        return X[self.goal_idx, -1, :] - self.goal[:, None]
+
+    def value(self, X, U, lam=None, rho=0.0):
+        """X: (n, T+1, P), U: (m, T, P) -> cost per trajectory (P,)"""
+        dx = X - self.x_ref[:, None, None]
+        J = 0.5 * torch.einsum("itp,ij,jtp->p", dx[:, :-1], self.Q, dx[:, :-1])
+        J = J + 0.5 * torch.einsum("itp,ij,jtp->p", U, self.R, U)
+        J = J + 0.5 * torch.einsum("ip,ij,jp->p", dx[:, -1], self.QT, dx[:, -1])
+        if self.goal_idx is not None and lam is not None:
+            c = self.constraint(X)
+            J = J + (lam * c).sum(0) + 0.5 * rho * (c * c).sum(0)
+        return J
+
+    def expansion(self, X, U, lam=None, rho=0.0):
+        """quadratic model per knot in the library's layout (column-major flattening, batch last)"""
+        n, m = self.n, self.m
+        T, P = U.shape[1], U.shape[2]
+        dx = X - self.x_ref[:, None, None]
+        lx = torch.einsum("ij,jtp->itp", self.Q, dx[:, :-1]).contiguous()
+        lu = torch.einsum("ij,jtp->itp", self.R, U).contiguous()
+        lxx = self.Q.T.reshape(n * n, 1, 1).expand(n * n, T, P).contiguous()
+        luu = self.R.T.reshape(m * m, 1, 1).expand(m * m, T, P).contiguous()
+        lux = torch.zeros(m * n, T, P, dtype=torch.float64, device=X.device)
+        Vxx = self.QT.clone()[:, :, None].repeat(1, 1, P)
+        Vx = torch.einsum("ij,jp->ip", self.QT, dx[:, -1])
+        if self.goal_idx is not None and lam is not None:
+            c = self.constraint(X)
+            Vx[self.goal_idx] += lam + rho * c
+            Vxx[self.goal_idx, self.goal_idx] += rho
+        VxxT = Vxx.transpose(0, 1).reshape(n * n, P).contiguous()     # column-major flattening
+        return lxx, luu, lux, lx, lu, VxxT, Vx.contiguous()
+
+
+class ILQR:
+    """B trajectory optimisations in lockstep."""
+
+    def __init__(self, im: ImplicitDynamics, objective: QuadraticObjective, T,
+                 alphas=tuple(2.0 ** -i for i in range(11)), reg=1e-6, c1=1e-4):
+        self.im, self.obj, self.T = im, objective, T
+        self.n, self.m = 2 * im.model.nq, im.model.nu
+        self.alphas = torch.tensor(alphas, dtype=torch.float64, device=im.device)
+        self.reg, self.c1 = reg, c1
+
+    # -- the three device steps ----------------------------------------------------------------
+    def linearize(self, x1, U):
+        X, A, Bm, st, it, _ = self.im.rollout(x1, U)
+        return X, A, Bm, st
+
+    def backward(self, A, Bm, quad, reg):
+        lxx, luu, lux, lx, lu, VxxT, VxT = quad
+        n, m, T = self.n, self.m, self.T
+        B = A.shape[-1]
+        im = self.im
+        im._use_current_stream()
+        # rollout returns (row, col, T, B) views of column-major buffers: flatten back to (n*n, T, B)
+        Af = A.transpose(0, 1).reshape(n * n, T, B).contiguous()
+        Bf = Bm.transpose(0, 1).reshape(n * m, T, B).contiguous()
+        K = torch.empty(m * n, T, B, dtype=torch.float64, device=im.device)
+        k = torch.empty(m, T, B, dtype=torch.float64, device=im.device)
+        dV = torch.empty(2, B, dtype=torch.float64, device=im.device)
+        st = torch.empty(B, dtype=torch.int32, device=im.device)
+        im.lib.check(im.lib.cdll.od_ilqr_backward(im._h, B, T, n, m, _ptr(Af), _ptr(Bf), _ptr(lxx), _ptr(luu), _ptr(lux),
+                                                  _ptr(lx), _ptr(lu), _ptr(VxxT), _ptr(VxT), float(reg), _ptr(K), _ptr(k), _ptr(dV), _ptr(st)))
+        return K, k, dV, st
+
+    def forward(self, x1, X, U, K, k):
+        """all step sizes at once -> Xc (n, T+1, nalpha*B), Uc (m, T, nalpha*B)"""
+        n, m, T = self.n, self.m, self.T
+        B, na = x1.shape[-1], self.alphas.numel()
+        im = self.im
+        im._use_current_stream()
+        Xc = torch.empty(n, T + 1, na * B, dtype=torch.float64, device=im.device)
+        Uc = torch.empty(m, T, na * B, dtype=torch.float64, device=im.device)
+        st = torch.empty(T, na * B, dtype=torch.int32, device=im.device)
+        im.lib.check(im.lib.cdll.od_rollout_policy(im._h, B, T, na, _ptr(self.alphas), _ptr(x1.contiguous()), _ptr(X.contiguous()),
+                                                   _ptr(U.contiguous()), _ptr(K), _ptr(k), _ptr(Xc), _ptr(Uc), _ptr(st), 0))
+        return Xc, Uc, st
+
+    # -- solver --------------------------------------------------------------------------------
+    def solve(self, x1, U0, max_iter=50, max_al_iter=1, rho_init=1.0, rho_scale=10.0, con_tol=1e-3, obj_tol=1e-6, verbose=False):
+        im, obj = self.im, self.obj
+        x1 = im._prep(x1)
+        U = im._prep(U0).clone()
+        B, na = x1.shape[-1], self.alphas.numel()
+        lam = None
+        rho = 0.0
+        if obj.goal_idx is not None:
+            lam = torch.zeros(obj.goal_idx.numel(), B, dtype=torch.float64, device=im.device)
+            rho = rho_init
+        history = []
+        X, A, Bm, st = self.linearize(x1, U)
+        for al in range(max_al_iter):
+            J = obj.value(X, U, lam, rho)
+            reg = torch.full((1,), self.reg).item()
+            for it in range(max_iter):
+                quad = obj.expansion(X, U, lam, rho)
+                K, k, dV, bst = self.backward(A, Bm, quad, reg)
+                Xc, Uc, cst = self.forward(x1, X, U, K, k)
+                Jc = obj.value(Xc, Uc, None if lam is None else lam.repeat(1, na), rho).view(na, B)
+                ok_roll = ((cst & 1) == 1).all(0).view(na, B)
+                expected = self.alphas[:, None] * dV[0][None, :] + self.alphas[:, None] ** 2 * dV[1][None, :]
+                accept = ok_roll & torch.isfinite(Jc) & (Jc <= J[None, :] + self.c1 * expected)
+                first = torch.where(accept.any(0), accept.float().argmax(0), torch.full((B,), -1, device=im.device, dtype=torch.long))
+                took = first >= 0
+                sel = torch.clamp(first, min=0) * B + torch.arange(B, device=im.device)
+                U = torch.where(took[None, None, :], Uc[:, :, sel], U)
+                Jn = torch.where(took, Jc.reshape(-1)[sel], J)
+                dJ = (J - Jn)
+                X, A, Bm, st = self.linearize(x1, U)
+                J = obj.value(X, U, lam, rho)
+                history.append(J.clone())
+                if verbose:
+                    print("al %d it %d  J mean %.6g  accepted %d/%d  max dJ %.3g" % (al, it, J.mean().item(), int(took.sum()), B, dJ.max().item()))
+                if not took.any():
+                    reg = min(reg * 10.0, 1e6)
+                    if reg >= 1e6:
+                        break
+                else:
+                    reg = max(reg / 5.0, self.reg)
+                if took.any() and dJ.max().item() < obj_tol:
+                    break
+            if lam is None:
+                break
+            c = obj.constraint(X)
+            if c.abs().max().item() < con_tol:
+                break
+            lam = lam + rho * c
+            rho = rho * rho_scale
+        return X, U, J, history

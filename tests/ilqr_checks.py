@@ -1,0 +1,76 @@
+"""iLQR checks shared by the CPU (host-emulation) and GPU tiers."""
+import numpy as np
+import torch
+
+import parity_checks as P
+from optimization_dynamics_amd import ilqr as IL, models
+from oracle import ilqr_np
+
+
+def cartpole_problem(lib, device, B, T, seed=0):
+    """cartpole with joint friction (examples/cartpole.jl:15-21 model/h/friction): move the cart 0.3 m with
+    the pole hanging, quadratic costs -- a task iLQR solves in a handful of iterations"""
+    im = P.make_im("cartpole_friction", lib, device)
+    n, m = 4, 1
+    Q = np.diag([0.0, 0.1, 0.0, 0.1]); R = np.diag([0.01]); QT = np.diag([1.0, 1.0, 1.0, 1.0]) * 100
+    goal = np.array([0.3, 0.0, 0.3, 0.0])
+    obj = IL.QuadraticObjective(Q, R, QT, x_ref=goal, goal_idx=[0, 1, 2, 3], goal=goal, device=device)
+    rng = np.random.default_rng(seed)
+    x1 = np.zeros((n, B)) + rng.normal(0, 0.01, (n, B)); x1[2:] = x1[:2]
+    # start above the static-friction threshold (mu (mp+mc) g h = 0.2): a stuck cart has dx/du = 0
+    U0 = 0.4 + 1e-2 * rng.normal(size=(m, T, B))
+    return im, obj, x1, U0
+
+
+def check_backward_and_forward(oracle, lib, device):
+    B, T = 6, 12
+    im, obj, x1, U0 = cartpole_problem(lib, device, B, T)
+    solver = IL.ILQR(im, obj, T)
+    x1t, Ut = torch.tensor(x1, device=device), torch.tensor(U0, device=device)
+    X, A, Bm, st = solver.linearize(x1t, Ut)
+    lam = torch.zeros(4, B, dtype=torch.float64, device=device)
+    quad = obj.expansion(X, Ut, lam, 1.0)
+    K, k, dV, bst = solver.backward(A, Bm, quad, 1e-6)
+    assert (bst == 1).all()
+    lxx, luu, lux, lx, lu, VxxT, VxT = [q.cpu().numpy() for q in quad]
+    An, Bn = A.cpu().numpy(), Bm.cpu().numpy()
+    n, m = 4, 1
+    for b in range(B):
+        Kr, kr, dVr = ilqr_np.backward(
+            np.moveaxis(An[:, :, :, b], 2, 0), np.moveaxis(Bn[:, :, :, b], 2, 0),
+            np.moveaxis(lxx[:, :, b].reshape(n, n, T, order="F"), 2, 0), np.moveaxis(luu[:, :, b].reshape(m, m, T, order="F"), 2, 0),
+            np.moveaxis(lux[:, :, b].reshape(m, n, T, order="F"), 2, 0), lx[:, :, b].T, lu[:, :, b].T,
+            VxxT[:, b].reshape(n, n, order="F"), VxT[:, b], 1e-6)
+        Kd = np.moveaxis(K.cpu().numpy()[:, :, b].reshape(m, n, T, order="F"), 2, 0)
+        assert np.abs(Kd - Kr).max() < 1e-8 * max(1.0, np.abs(Kr).max())
+        assert np.abs(k.cpu().numpy()[:, :, b].T - kr).max() < 1e-8 * max(1.0, np.abs(kr).max())
+        assert np.abs(dV.cpu().numpy()[:, b] - dVr).max() < 1e-8 * max(1.0, np.abs(dVr).max())
+    # forward pass: alpha = 0 candidate reproduces the nominal, every candidate equals an open-loop
+    # rollout of the controls it reports
+    solver.alphas = torch.tensor([1.0, 0.25, 0.0], dtype=torch.float64, device=device)
+    Xc, Uc, cst = solver.forward(x1t, X, Ut, K, k)
+    na = 3
+    assert (Xc[:, :, 2 * B:] - X).abs().max().item() < 1e-12 and (Uc[:, :, 2 * B:] - Ut).abs().max().item() < 1e-12
+    Xo = im.rollout(x1t.repeat(1, na), Uc, grads=False)[0]
+    assert (Xo - Xc).abs().max().item() < 1e-10
+    # policy law
+    t, a, b = 3, 1, 2
+    Kt = K[:, t, b].view(n, m).T
+    u_expect = Ut[:, t, b] + 0.25 * k[:, t, b] + Kt @ (Xc[:, t, a * B + b] - X[:, t, b])
+    assert (u_expect - Uc[:, t, a * B + b]).abs().max().item() < 1e-12
+
+
+def check_solver_decreases_cost(lib, device, B=8, T=25):
+    im, obj, x1, U0 = cartpole_problem(lib, device, B, T, seed=1)
+    solver = IL.ILQR(im, obj, T)
+    x1t, Ut = torch.tensor(x1, device=device), torch.tensor(U0, device=device)
+    X0 = solver.linearize(x1t, Ut)[0]
+    J0 = obj.value(X0, Ut)
+    X, U, J, hist = solver.solve(x1t, Ut, max_iter=15, max_al_iter=1)
+    Jf = obj.value(X, U)
+    assert torch.isfinite(Jf).all()
+    assert (Jf <= J0 + 1e-9).all() and (Jf < 0.2 * J0).float().mean().item() > 0.7
+    # the returned trajectory is dynamically consistent with its controls
+    Xr = im.rollout(x1t, U, grads=False)[0]
+    assert (Xr - X).abs().max().item() < 1e-10
+    return J0, Jf

@@ -1,0 +1,24 @@
+"""iLQR around the path: backward pass against the numpy restatement, forward pass
+consistency, and a decreasing cost on cartpole with joint friction -- CPU tier on the host emulation,
+GPU tier through the shipped library."""
+import pytest
+
+import ilqr_checks as C
+
+
+def test_backward_forward_cpu(oracle, emu_lib):
+    C.check_backward_and_forward(oracle, emu_lib, "cpu")
+
+
+def test_solver_decreases_cost_cpu(emu_lib):
+    C.check_solver_decreases_cost(emu_lib, "cpu", B=4, T=20)
+
+
+@pytest.mark.gpu
+def test_backward_forward_gpu(oracle, gpu_lib):
+    C.check_backward_and_forward(oracle, gpu_lib, "cuda:0")
+
+
+@pytest.mark.gpu
+def test_solver_decreases_cost_gpu(gpu_lib):
+    J0, Jf = C.check_solver_decreases_cost(gpu_lib, "cuda:0", B=256, T=50)
