@@ -155,6 +155,15 @@ int od_ip_solve(od_handle h, long B, const void* z0, const void* theta, void* z,
 int od_rocket(od_handle h, long B, int project, const void* x, const void* u, void* y, void* dx,
               void* du, void* uproj, int* status);
 
+/* iLQR.rollout / forward pass over f_rocket (project = 0) or f_rocket_proj (project = 1), time recursion on the
+ * device (examples/rocket.jl:29-41,118).  nalpha = 0: open loop, controls ubar (3 per knot, T*B knots), B
+ * trajectories.  nalpha > 0: closed loop u = ubar + alpha k + K (x - xbar) for nalpha step sizes (candidate
+ * p = a*B + b; xbar 12 per slot ((T+1)*B), K 3 x 12 col-major and kff 3 per nominal knot, alphas on the device).
+ * X: 12 per slot ((T+1)*P slots, P = B or B*nalpha), U (optional): controls applied before projection, 3 per
+ * candidate knot; status per candidate knot. */
+int od_rocket_rollout(od_handle h, long B, int T, int nalpha, const void* alphas, int project, const void* x1,
+                      const void* xbar, const void* ubar, const void* K, const void* kff, void* X, void* U, int* status);
+
 /* host-pointer scalar path (B = 1), the plumbing config: reference signatures f(d,model,x,u,w),
  * fx(dx,...), fu(du,...) (src/dynamics.jl:81,96,116).  Column-major, every entry written. */
 int od_f_host(od_handle h, const double* x, const double* u, double* d);

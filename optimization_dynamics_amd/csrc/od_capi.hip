@@ -373,6 +373,51 @@ template <class T> static int rocket_impl(od_handle h, long B, int project, cons
 }
 
 
+template <class T> static RocketArgs<T> rocket_args(od_handle h, long B, int project, int want_grad) {
+  RocketArgs<T> a;
+  a.B = B;
+  a.h = (T)h->h;
+  a.u_max = (T)h->u_max;
+  a.opts_dyn = to_opts<T>(h->opts);
+  od_options po;
+  defaults_of(vt_rocket_projection(), &po);
+  if (h->dtype == OD_F32) po.r_tol = std::fmax(po.r_tol, (double)h->opts.r_tol);   // tolerances reachable in fp32
+  a.opts_proj = to_opts<T>(po);
+  a.project = project;
+  a.want_grad = want_grad;
+  a.x.p = nullptr; a.u.p = nullptr; a.y.p = nullptr; a.dx.p = nullptr; a.du.p = nullptr; a.uproj.p = nullptr; a.status.p = nullptr;
+  return a;
+}
+
+template <class T> static int rocket_rollout_impl(od_handle h, long B, int Tn, int nalpha, const void* alphas, int project,
+                                                  const void* x1, const void* xbar, const void* ubar, const void* K,
+                                                  const void* kff, void* X, void* U, int* status) {
+  const int L = h->layout;
+  const long P = nalpha > 0 ? B * nalpha : B, Kn = (long)Tn * B, Kc = (long)Tn * P;
+  RocketRolloutArgs<T> ra;
+  ra.a = rocket_args<T>(h, P, project, 0);
+  ra.a.x = mkcview<T>(x1, 12, B, L);
+  View<T> xv = mkview<T>(X, 12, (long)(Tn + 1) * P, L);
+  ra.x0 = xv;
+  ra.a.y = xv;
+  ra.a.y.p += (long)P * xv.sb;
+  ra.a.status = mkview<int>(status, 1, Kc, L);
+  ra.Tn = Tn;
+  ra.Bnom = B;
+  ra.nalpha = nalpha;
+  ra.alphas = (const T*)alphas;
+  ra.xbar = mkcview<T>(xbar, 12, (long)(Tn + 1) * B, L);
+  ra.ubar = mkcview<T>(ubar, 3, Kn, L);
+  ra.K = mkcview<T>(K, 36, Kn, L);
+  ra.kff = mkcview<T>(kff, 3, Kn, L);
+  ra.U = mkview<T>(U, 3, Kc, L);
+  hipError_t e;
+  if constexpr (sizeof(T) == 8) e = launch_rocket_rollout64(ra, ppw_of(h, P), h->stream);
+  else e = launch_rocket_rollout32(ra, ppw_of(h, P), h->stream);
+  if (e != hipSuccess) return fail(OD_ERR_HIP, std::string("od_rocket_rollout launch: ") + hipGetErrorString(e));
+  return OD_OK;
+}
+
 extern "C" {
 
 int od_version(void) { return 100; }
@@ -674,6 +719,17 @@ int od_ip_solve(od_handle h, long B, const void* z0, const void* theta, void* z,
     OD_HIP(vt->raw32(a, ppw_of(h, B), h->stream));
   }
   return OD_OK;
+}
+
+int od_rocket_rollout(od_handle h, long B, int T, int nalpha, const void* alphas, int project, const void* x1,
+                      const void* xbar, const void* ubar, const void* K, const void* kff, void* X, void* U, int* status) {
+  if (!h) return fail(OD_ERR_INVALID, "od_rocket_rollout: null handle");
+  if (h->vt->id != OD_ROCKET_DYNAMICS) return fail(OD_ERR_UNSUPPORTED, "od_rocket_rollout: needs an OD_ROCKET_DYNAMICS handle");
+  if (B <= 0 || T <= 0) return OD_OK;
+  if (!x1 || !ubar || !X) return fail(OD_ERR_INVALID, "od_rocket_rollout: null x1/ubar/X");
+  if (nalpha > 0 && (!alphas || !xbar || !K || !kff)) return fail(OD_ERR_INVALID, "od_rocket_rollout: policy arguments missing");
+  if (h->dtype == OD_F64) return rocket_rollout_impl<double>(h, B, T, nalpha, alphas, project, x1, xbar, ubar, K, kff, X, U, status);
+  return rocket_rollout_impl<float>(h, B, T, nalpha, alphas, project, x1, xbar, ubar, K, kff, X, U, status);
 }
 
 int od_rocket(od_handle h, long B, int project, const void* x, const void* u, void* y, void* dx, void* du,

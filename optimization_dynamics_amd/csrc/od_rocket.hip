@@ -21,4 +21,17 @@ hipError_t launch_rocket32(const RocketArgs<float>& a, int ppw, hipStream_t s) {
   return hipGetLastError();
 }
 
+template <class T> __global__ __launch_bounds__(OD_BLOCK) void k_rocket_rollout(RocketRolloutArgs<T> a, LaneMap lm) {
+  const long p = lm.problem(blockIdx.x, threadIdx.x);
+  if (lm.active(threadIdx.x) && p < a.a.B) unit_rocket_rollout<Model_rocket_dynamics, Model_rocket_projection, T>(a, p);
+}
+hipError_t launch_rocket_rollout64(const RocketRolloutArgs<double>& a, int ppw, hipStream_t s) {
+  hipLaunchKernelGGL((k_rocket_rollout<double>), od_grid(a.a.B, ppw), dim3(OD_BLOCK), 0, s, a, LaneMap{ppw});
+  return hipGetLastError();
+}
+hipError_t launch_rocket_rollout32(const RocketRolloutArgs<float>& a, int ppw, hipStream_t s) {
+  hipLaunchKernelGGL((k_rocket_rollout<float>), od_grid(a.a.B, ppw), dim3(OD_BLOCK), 0, s, a, LaneMap{ppw});
+  return hipGetLastError();
+}
+
 }  // namespace od

@@ -363,12 +363,9 @@ template <class T> struct RocketDynSink {
   }
 };
 
-template <class MD, class MP, class T> OD_HD void unit_rocket(const RocketArgs<T>& a, long b) {
-  T x[12], u[3];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) x[i] = a.x.at(i, b);
-#pragma unroll
-  for (int i = 0; i < 3; ++i) u[i] = a.u.at(i, b);
+// one rocket knot: (x, u) in registers -> y in registers; per-knot outputs (dx, du, uproj, status) at index b
+template <class MD, class MP, class T>
+OD_HD void rocket_knot(const RocketArgs<T>& a, long b, const T* x, T* u, T* y) {
   int st = 0;
   T dproj[9];   // d uproj / d u  (3x3 col-major)
   if (a.project) {
@@ -387,9 +384,9 @@ template <class MD, class MP, class T> OD_HD void unit_rocket(const RocketArgs<T
     if (a.uproj.ok()) { a.uproj.at(0, b) = u[0]; a.uproj.at(1, b) = u[1]; a.uproj.at(2, b) = u[2]; }
   }
   // f_rocket (dynamics.jl:101-114): z0 = x, theta = [x; u; h]
-  T th[MD::NTH], z[MD::NZ];
+  T th[MD::NTH];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) { th[i] = x[i]; z[i] = x[i]; }
+  for (int i = 0; i < 12; ++i) { th[i] = x[i]; y[i] = x[i]; }
   th[12] = u[0]; th[13] = u[1]; th[14] = u[2]; th[15] = a.h;
   // du with projection needs the 12x3 block times dproj: collect the u-columns in registers
   T dyn_u[36];
@@ -397,12 +394,8 @@ template <class MD, class MP, class T> OD_HD void unit_rocket(const RocketArgs<T
 #pragma unroll
   for (int i = 0; i < 36; ++i) dyn_u[i] = T(0);
   int it[2];
-  const int sd = ip_step_grad<MD>(a.opts_dyn, th, z, true, a.want_grad != 0, ds, it);
+  const int sd = ip_step_grad<MD>(a.opts_dyn, th, y, true, a.want_grad != 0, ds, it);
   st |= (sd & 7);
-  if (a.y.ok()) {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) a.y.at(i, b) = z[i];
-  }
   if (a.want_grad && a.du.ok()) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -419,6 +412,72 @@ template <class MD, class MP, class T> OD_HD void unit_rocket(const RocketArgs<T
     }
   }
   if (a.status.ok()) a.status.at(0, b) = st;
+}
+
+template <class MD, class MP, class T> OD_HD void unit_rocket(const RocketArgs<T>& a, long b) {
+  T x[12], u[3], y[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) x[i] = a.x.at(i, b);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) u[i] = a.u.at(i, b);
+  rocket_knot<MD, MP, T>(a, b, x, u, y);
+  if (a.y.ok()) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) a.y.at(i, b) = y[i];
+  }
+}
+
+// rocket rollouts (iLQR.rollout / forward pass over f_rocket or f_rocket_proj, examples/rocket.jl:29-41,118):
+// candidate p = a*Bnom + b; with nalpha = 0 the rollout is open loop (controls from ubar, knot index t*Bnom + b),
+// otherwise u_t = ubar_t + alpha k_t + K_t (x_t - xbar_t).  State only (a.want_grad = 0); X gets T+1 slots.
+template <class T> struct RocketRolloutArgs {
+  RocketArgs<T> a;       // a.B = P candidates; a.x = x1 of the Bnom nominal trajectories; a.y = X view shifted by one slot
+  View<T> x0;            // slot 0 of X
+  int Tn;
+  long Bnom;
+  int nalpha;
+  const T* alphas;
+  View<const T> xbar, ubar, K, kff;
+  View<T> U;             // controls applied (before projection), per candidate knot
+};
+
+template <class MD, class MP, class T> OD_HD void unit_rocket_rollout(const RocketRolloutArgs<T>& ra, long p) {
+  const RocketArgs<T>& a = ra.a;
+  const long b = ra.nalpha > 0 ? p % ra.Bnom : p;
+  const T alpha = ra.nalpha > 0 ? ra.alphas[p / ra.Bnom] : T(0);
+  T x[12], u[3], y[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) x[i] = a.x.at(i, b);
+  if (ra.x0.ok()) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) ra.x0.at(i, p) = x[i];
+  }
+  for (int t = 0; t < ra.Tn; ++t) {
+    const long kn = (long)t * ra.Bnom + b, kc = (long)t * a.B + p;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) u[j] = ra.ubar.at(j, kn);
+    if (ra.nalpha > 0) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) u[j] += alpha * ra.kff.at(j, kn);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const T dxi = x[i] - ra.xbar.at(i, kn);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) u[j] += ra.K.at(j + 3 * i, kn) * dxi;
+      }
+    }
+    if (ra.U.ok()) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) ra.U.at(j, kc) = u[j];
+    }
+    rocket_knot<MD, MP, T>(a, kc, x, u, y);
+    if (a.y.ok()) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) a.y.at(i, kc) = y[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) x[i] = y[i];
+  }
 }
 
 }  // namespace od

@@ -70,10 +70,14 @@ class QuadraticObjective:
 class ILQR:
     """B trajectory optimisations in lockstep."""
 
-    def __init__(self, im: ImplicitDynamics, objective: QuadraticObjective, T,
+    def __init__(self, im, objective: QuadraticObjective, T,
                  alphas=tuple(2.0 ** -i for i in range(11)), reg=1e-6, c1=1e-4):
+        """im: an ImplicitDynamics (mechanical models) or a rocket.RocketDynamics"""
         self.im, self.obj, self.T = im, objective, T
-        self.n, self.m = 2 * im.model.nq, im.model.nu
+        if isinstance(im, ImplicitDynamics):
+            self.n, self.m = 2 * im.model.nq, im.model.nu
+        else:
+            self.n, self.m = im.n, im.m
         self.alphas = torch.tensor(alphas, dtype=torch.float64, device=im.device)
         self.reg, self.c1 = reg, c1
 
@@ -104,6 +108,8 @@ class ILQR:
         n, m, T = self.n, self.m, self.T
         B, na = x1.shape[-1], self.alphas.numel()
         im = self.im
+        if not isinstance(im, ImplicitDynamics):
+            return im.rollout_policy(x1, X, U, K, k, self.alphas)
         im._use_current_stream()
         Xc = torch.empty(n, T + 1, na * B, dtype=torch.float64, device=im.device)
         Uc = torch.empty(m, T, na * B, dtype=torch.float64, device=im.device)

@@ -72,6 +72,60 @@ class RocketInfo:
         return Y, DX, DU, UP, st
 
 
+def _rocket_rollout(info, x1, U, project, policy=None):
+    """time recursion on the device.  x1 (12, B), U = ubar (3, T, B).
+    policy = (alphas (na,), xbar (12, T+1, B), K (36, T, B), k (3, T, B)) for the closed-loop forward pass.
+    -> X (12, T+1, P), Uapplied (3, T, P), status (T, P) with P = B or na*B"""
+    info._use_current_stream()
+    dt, dev = info.dtype, info.device
+    x1 = x1.to(device=dev, dtype=dt).contiguous()
+    U = U.to(device=dev, dtype=dt).contiguous()
+    T, B = U.shape[1], U.shape[2]
+    if policy is None:
+        na, P = 0, B
+    else:
+        alphas, xbar, K, k = [t.to(device=dev, dtype=dt).contiguous() for t in policy]
+        na, P = alphas.numel(), alphas.numel() * B
+    X = torch.empty(12, T + 1, P, dtype=dt, device=dev)
+    Ua = torch.empty(3, T, P, dtype=dt, device=dev)
+    st = torch.empty(T, P, dtype=torch.int32, device=dev)
+    if policy is None:
+        rc = info.lib.cdll.od_rocket_rollout(info._h, B, T, 0, 0, 1 if project else 0, _ptr(x1), 0, _ptr(U), 0, 0, _ptr(X), _ptr(Ua), _ptr(st))
+    else:
+        rc = info.lib.cdll.od_rocket_rollout(info._h, B, T, na, _ptr(alphas), 1 if project else 0, _ptr(x1), _ptr(xbar), _ptr(U),
+                                             _ptr(K), _ptr(k), _ptr(X), _ptr(Ua), _ptr(st))
+    info.lib.check(rc)
+    return X, Ua, st
+
+
+class RocketDynamics:
+    """iLQR view of a RocketInfo (f_rocket / f_rocket_proj as the dynamics of examples/rocket.jl:29-41):
+    the interface optimization_dynamics_amd.ilqr.ILQR expects (n, m, rollout, rollout_policy)."""
+
+    def __init__(self, info, project=True):
+        self.info, self.project = info, project
+        self.n, self.m = 12, 3
+        self.device, self.lib, self._h = info.device, info.lib, info._h
+        self._use_current_stream = info._use_current_stream
+
+    def _prep(self, t):
+        return t.to(device=self.device, dtype=torch.float64).contiguous()
+
+    def rollout(self, x1, U, grads=True):
+        X, Ua, st = _rocket_rollout(self.info, x1, U, self.project)
+        A = Bm = None
+        if grads:
+            T, B = U.shape[1], U.shape[2]
+            Y, DX, DU, UP, s2 = self.info.solve(X[:, :-1].reshape(12, T * B), U.reshape(3, T * B), project=self.project, grads=True)
+            A = DX.reshape(12, 12, T, B).double()
+            Bm = DU.reshape(12, 3, T, B).double()
+        return X.double(), A, Bm, st, None, None
+
+    def rollout_policy(self, x1, X, U, K, k, alphas):
+        Xc, Uc, st = _rocket_rollout(self.info, x1, U, self.project, policy=(alphas, X, K, k))
+        return Xc.double(), Uc.double(), st
+
+
 def _scalar(info, x, u, project, grads):
     X = torch.tensor(np.asarray(x, dtype=np.float64)).reshape(12, 1)
     U = torch.tensor(np.asarray(u, dtype=np.float64)).reshape(3, 1)

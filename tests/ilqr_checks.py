@@ -74,3 +74,44 @@ def check_solver_decreases_cost(lib, device, B=8, T=25):
     Xr = im.rollout(x1t, U, grads=False)[0]
     assert (Xr - X).abs().max().item() < 1e-10
     return J0, Jf
+
+
+def rocket_problem(lib, device, B, T, dtype=torch.float64, seed=0):
+    """rocket soft landing with the thrust-cone projection on the path (examples/rocket.jl:15-50 sizes:
+    h=0.05, u_max=12.5); quadratic costs"""
+    from optimization_dynamics_amd import rocket as rk
+    info = rk.RocketInfo(models.rocket, 12.5, 0.05, dtype=dtype, device=device, lib=lib)
+    dyn = rk.RocketDynamics(info, project=True)
+    goal = np.zeros(12); goal[2] = 2.0
+    Q = np.diag([1e-2] * 3 + [1e-1] * 3 + [1e-2] * 3 + [1e-1] * 3)
+    R = np.diag([1e-2, 1e-2, 1e-3])
+    QT = np.diag([10.0] * 12)
+    obj = IL.QuadraticObjective(Q, R, QT, x_ref=goal, device=device)
+    rng = np.random.default_rng(seed)
+    x1 = np.zeros((12, B)); x1[0] = 1.0; x1[1] = 0.5; x1[2] = 4.0
+    x1 += rng.normal(0, 0.05, (12, B)); x1[3:6] *= 0.2
+    U0 = np.zeros((3, T, B)); U0[2] = 9.81 + 0.1 * rng.normal(size=(T, B))      # hover thrust (mass 1)
+    U0[:2] = 1e-3 * rng.normal(size=(2, T, B))
+    return dyn, obj, x1, U0
+
+
+def check_rocket_ilqr(oracle, lib, device, B=4, T=20, dtype=torch.float64):
+    dyn, obj, x1, U0 = rocket_problem(lib, device, B, T, dtype=dtype)
+    x1t, Ut = torch.tensor(x1, device=device), torch.tensor(U0, device=device)
+    # rollout == chained f_rocket_proj of the oracle
+    X, A, Bm, st, _, _ = dyn.rollout(x1t, Ut)
+    if dtype == torch.float64:
+        for b in range(min(B, 2)):
+            x = x1[:, b].copy()
+            for t in range(T):
+                ok, x, dx, du = oracle.rocket_proj(0.05, 12.5, x, U0[:, t, b])
+                # the projected control is only kappa_tol = 1e-4 accurate by construction and its line search has
+                # rounding-level ties (parity_checks.check_rocket): the chained states agree to that level
+                assert np.abs(X[:, t + 1, b].cpu().numpy() - x).max() < 1e-3 * max(1, np.abs(x).max())
+            assert np.abs(A[:, :, T - 1, b].cpu().numpy() - dx).max() < 2e-2 * max(1, np.abs(dx).max())
+    solver = IL.ILQR(dyn, obj, T)
+    J0 = obj.value(X, Ut.double())
+    Xs, Us, J, hist = solver.solve(x1t, Ut, max_iter=10)
+    Jf = obj.value(Xs, Us)
+    assert torch.isfinite(Jf).all() and (Jf <= J0 + 1e-6).all() and (Jf < 0.8 * J0).float().mean().item() > 0.7
+    return J0, Jf

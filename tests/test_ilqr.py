@@ -22,3 +22,19 @@ def test_backward_forward_gpu(oracle, gpu_lib):
 @pytest.mark.gpu
 def test_solver_decreases_cost_gpu(gpu_lib):
     J0, Jf = C.check_solver_decreases_cost(gpu_lib, "cuda:0", B=256, T=50)
+
+
+def test_rocket_projection_ilqr_cpu(oracle, emu_lib):
+    """BASELINE config 5 (reduced): rocket thrust-cone SOCP step inside the iLQR loop with implicit gradients"""
+    C.check_rocket_ilqr(oracle, emu_lib, "cpu", B=3, T=15)
+
+
+@pytest.mark.gpu
+def test_rocket_projection_ilqr_gpu_f64(oracle, gpu_lib):
+    C.check_rocket_ilqr(oracle, gpu_lib, "cuda:0", B=64, T=40)
+
+
+@pytest.mark.gpu
+def test_rocket_projection_ilqr_gpu_f32(oracle, gpu_lib):
+    import torch
+    C.check_rocket_ilqr(oracle, gpu_lib, "cuda:0", B=64, T=40, dtype=torch.float32)
