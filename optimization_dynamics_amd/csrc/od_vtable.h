@@ -48,17 +48,21 @@ struct LaneMap {
   int ppw;                                  // problems per wavefront, power of two in [1, 64]
   // thread t of a block: wavefront t/64, lane t%64 (blocks are 1 or 4 wavefronts)
   __host__ __device__ long problem(unsigned block, unsigned thread, unsigned block_threads = 64) const {
-    return ((long)block * (block_threads / 64) + thread / 64) * ppw + (thread & 63);
+    return ((long)block * (block_threads / 64) + thread / 64) * ppw + ((thread & 63) % ppw);
   }
-  __host__ __device__ bool active(unsigned thread) const { return (int)(thread & 63) < ppw; }
+  // At least 16 lanes execute: with ppw < 16 the lanes ppw..15 repeat the problems of lanes 0..ppw-1 (same
+  // loads, same arithmetic, identical stores).  Measured on MI355X (profiles/): this kernel runs 2.5x SLOWER
+  // per wavefront with 8 or 4 active lanes than with 16 (SQ_WAIT_INST_ANY 56 % of wave cycles), so fewer
+  // problems per wavefront only pay off if a full 16-lane group keeps executing.
+  __host__ __device__ bool active(unsigned thread) const { return (int)(thread & 63) < (ppw < 16 ? 16 : ppw); }
 };
 
 inline int od_auto_ppw(long n) {
-  // Measured on MI355X (profiles/): this fp64, register-heavy instruction stream stops scaling at
-  // about 256 resident wavefronts chip-wide (more wavefronts only add issue stalls), so aim at 256
-  // wavefronts and pack more problems per wavefront only beyond that.
+  // A wavefront is as slow as its slowest lane, so spread the batch: one wavefront per SIMD
+  // (256 CUs x 4 = 1024 wavefronts) before packing more problems into a wavefront.  (Two 512-register
+  // wavefronts cannot share a SIMD; measured: 2048 wavefronts take 1.7x longer than 1024.)
   long p = 1;
-  while (p < 64 && n / p > 256) p <<= 1;
+  while (p < 64 && n / p > 1024) p <<= 1;
   return (int)p;
 }
 inline dim3 od_grid(long n, int ppw) { return dim3((unsigned)((n + ppw - 1) / ppw)); }
