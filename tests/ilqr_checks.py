@@ -4,7 +4,6 @@ import torch
 
 import parity_checks as P
 from optimization_dynamics_amd import ilqr as IL, models
-from oracle import ilqr_np
 
 
 def cartpole_problem(lib, device, B, T, seed=0):
@@ -23,6 +22,7 @@ def cartpole_problem(lib, device, B, T, seed=0):
 
 
 def check_backward_and_forward(oracle, lib, device):
+    from oracle import ilqr_np          # numpy checker (test infrastructure)
     B, T = 6, 12
     im, obj, x1, U0 = cartpole_problem(lib, device, B, T)
     solver = IL.ILQR(im, obj, T)
