@@ -3,3 +3,9 @@ thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 int od_trace_flag = 0;
 extern "C" void od_emu_set_trace(int v) { od_trace_flag = v; }
 thread_local double od_lds[160 * 1024 / 8];   // emulated per-workgroup LDS (one workgroup per OpenMP thread at a time)
+
+// unit-test hooks for the scalar helpers of od_math.h (tests/test_models.py)
+#include "od_math.h"
+extern "C" void od_emu_sincos(const double* x, long n, double* s, double* c) {
+  for (long i = 0; i < n; ++i) od::od_sincos(x[i], s[i], c[i]);
+}
