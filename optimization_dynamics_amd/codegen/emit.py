@@ -364,7 +364,10 @@ class _Elim:
             L.append("}")
             self.fwd.append((pr, fw))
             self.bwd.append((pr, pc, ipval, us))
-        self.tail_rows = rows
+        # rows that share their index with a `tail_last` column (dynamics row i <-> configuration q_i) go
+        # last, in that order: the natural pivots then sit on the diagonal and the runtime search seldom
+        # has to exchange rows (od_lu_factor skips an exchange no lane of the wavefront needs)
+        self.tail_rows = [r for r in rows if r not in tail_last] + [r for r in tail_last if r in rows]
         self.tail_cols = [c for c in cols if c not in tail_last] + [c for c in cols if c in tail_last]
         self.m = len(rows)
         self.tail_base = self.slots

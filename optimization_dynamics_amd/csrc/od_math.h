@@ -136,6 +136,8 @@ template <class T, int N> OD_HD bool od_lu_factor(T* A, int* piv) {
   bool ok = true;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
+    // partial pivoting, ties to the diagonal.  The generated tail puts the natural pivots on the
+    // diagonal, and a whole exchange is skipped when no lane of the wavefront needs it.
     int p = k;
     T best = od_abs(A[k + N * k]);
 #pragma unroll
@@ -147,17 +149,22 @@ template <class T, int N> OD_HD bool od_lu_factor(T* A, int* piv) {
     ok = ok && (best > T(0));
     // exchange rows k and p of the ACTIVE part only (columns >= k); the multipliers already stored
     // in columns < k stay with their physical rows, and od_lu_solve replays the exchanges in order
+    if (p != k) {
 #pragma unroll
-    for (int i = k + 1; i < N; ++i) {
-      const bool sw = (p == i);
+      for (int i = k + 1; i < N; ++i) {
+        const bool sw = (p == i);
 #pragma unroll
-      for (int j = k; j < N; ++j) {
-        const T u = A[k + N * j], w = A[i + N * j];
-        A[k + N * j] = sw ? w : u;
-        A[i + N * j] = sw ? u : w;
+        for (int j = k; j < N; ++j) {
+          const T u = A[k + N * j], w = A[i + N * j];
+          A[k + N * j] = sw ? w : u;
+          A[i + N * j] = sw ? u : w;
+        }
       }
     }
-    const T inv = od_rcp(A[k + N * k]);
+    // a column that vanished entirely (a cone variable stepped exactly onto its boundary: tau rounds to
+    // 1 once the violation is below 1e-8) makes the system singular; its unknown is dropped (x_k = 0)
+    // so that the outputs stay finite, and the caller reports the knot through FACTOR_OK
+    const T inv = best > T(0) ? od_rcp(A[k + N * k]) : T(0);
     A[k + N * k] = inv;                       // the diagonal holds 1/u_kk
 #pragma unroll
     for (int i = k + 1; i < N; ++i) A[i + N * k] *= inv;

@@ -59,9 +59,13 @@ template <int N, class T> OD_HD T soc_step_one(const T* lam, const T* dlt, T tau
   const T rs = ld * ill;
   const T c = (ld * isq + dlt[0]) * od_rcp(l0 * isq + T(1));
   T nv = T(0);
+  if constexpr (N == 2) {
+    nv = od_abs(dlt[1] * isq - c * lam[1] * ill);     // the norm of a 1-vector: no square root
+  } else {
 #pragma unroll
-  for (int i = 1; i < N; ++i) { const T rv = dlt[i] * isq - c * lam[i] * ill; nv += rv * rv; }
-  nv = od_sqrt(nv);
+    for (int i = 1; i < N; ++i) { const T rv = dlt[i] * isq - c * lam[i] * ill; nv += rv * rv; }
+    nv = od_sqrt(nv);
+  }
   T a = T(1);
   if (nv - rs > T(0)) a = od_min(a, tau * od_rcp(nv - rs));
   return a;

@@ -9,3 +9,11 @@ thread_local double od_lds[160 * 1024 / 8];   // emulated per-workgroup LDS (one
 extern "C" void od_emu_sincos(const double* x, long n, double* s, double* c) {
   for (long i = 0; i < n; ++i) od::od_sincos(x[i], s[i], c[i]);
 }
+extern "C" int od_emu_lu6(const double* A, const double* b, double* x) {
+  double a[36]; int piv[6];
+  for (int i = 0; i < 36; ++i) a[i] = A[i];
+  for (int i = 0; i < 6; ++i) x[i] = b[i];
+  const bool ok = od::od_lu_factor<double, 6>(a, piv);
+  od::od_lu_solve<double, 6>(a, piv, x);
+  return ok ? 1 : 0;
+}

@@ -176,3 +176,30 @@ def test_device_sincos_accuracy(emu_lib):
     sb = np.empty(3); cb = np.empty(3)
     so.od_emu_sincos(big.ctypes.data_as(P), ctypes.c_long(3), sb.ctypes.data_as(P), cb.ctypes.data_as(P))
     assert np.all(np.isfinite(sb[:2])) and np.all(np.abs(sb[:2]) <= 1.0 + 1e-6)
+
+
+def test_tail_lu_against_numpy(emu_lib):
+    """od_math.h::od_lu_factor / od_lu_solve (the runtime-pivoted dense tail): random, badly scaled and
+    permutation-heavy 6x6 systems against numpy; an all-zero column is reported and leaves finite output."""
+    import ctypes
+    P = ctypes.POINTER(ctypes.c_double)
+    fn = emu_lib.cdll.od_emu_lu6
+    fn.restype = ctypes.c_int
+    rng = np.random.default_rng(3)
+    x = np.empty(6)
+    for trial in range(200):
+        A = rng.normal(size=(6, 6))
+        if trial % 3 == 1:
+            A *= 10.0 ** rng.integers(-20, 20, size=(1, 6))         # column scales as in the KKT tail
+        if trial % 3 == 2:
+            A = A[rng.permutation(6)] + np.diag(rng.normal(size=6) * 1e-8)
+        b = rng.normal(size=6)
+        Af = np.asfortranarray(A)
+        ok = fn(Af.ctypes.data_as(P), b.ctypes.data_as(P), x.ctypes.data_as(P))
+        assert ok == 1
+        ref = np.linalg.solve(A, b)
+        assert np.allclose(x, ref, rtol=1e-9 * max(1.0, np.linalg.cond(A / np.abs(A).max(0)) / 1e4), atol=0), trial
+    A = rng.normal(size=(6, 6)); A[:, 0] = 0.0
+    Af = np.asfortranarray(A)
+    ok = fn(Af.ctypes.data_as(P), b.ctypes.data_as(P), x.ctypes.data_as(P))
+    assert ok == 0 and np.all(np.isfinite(x)) and x[0] == 0.0
