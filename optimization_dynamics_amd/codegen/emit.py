@@ -59,12 +59,12 @@ class _DevicePrinter(C99CodePrinter):
             return "od_powi<%d>(%s)" % (int(e), self._print(b))
         if e.is_Integer and -12 <= int(e) <= -1:
             if int(e) == -1:
-                return "(T(1)/(%s))" % self._print(b)
-            return "(T(1)/od_powi<%d>(%s))" % (-int(e), self._print(b))
+                return "od_rcp(%s)" % self._print(b)
+            return "od_rcp(od_powi<%d>(%s))" % (-int(e), self._print(b))
         if e == sp.Rational(1, 2):
             return "od_sqrt(%s)" % self._print(b)
         if e == -sp.Rational(1, 2):
-            return "(T(1)/od_sqrt(%s))" % self._print(b)
+            return "od_rsqrt(%s)" % self._print(b)
         return "od_pow(%s, %s)" % (self._print(b), self._print(e))
 
     def _print_sin(self, expr):

@@ -31,19 +31,21 @@ template <class T> struct Opts {
 
 enum : int { OD_ST_EVAL_OK = 1, OD_ST_GRAD_OK = 2, OD_ST_FACTOR_OK = 4 };
 
+// max |r_i| over the equality / complementarity rows, NaN-sticky (a NaN residual must fail every
+// convergence and line-search test): hardware max drops NaNs, so a running sum carries them instead
 template <class M, class T> OD_HD T viol_eq(const T* r) {
-  T v = T(0);
+  T v = T(0), s = T(0);
 #pragma unroll
-  for (int i = 0; i < M::NEQ; ++i) { const T a = od_abs(r[M::EQUR[i]]); v = (a > v || a != a) ? a : v; }
-  return v;
+  for (int i = 0; i < M::NEQ; ++i) { const T a = od_abs(r[M::EQUR[i]]); v = od_fmax(v, a); s += a; }
+  return (s != s) ? s : v;
 }
 template <class M, class T> OD_HD T viol_bil(const T* r) {
-  T v = T(0);
+  T v = T(0), s = T(0);
   if constexpr (M::NBIL > 0) {
 #pragma unroll
-    for (int i = 0; i < M::NBIL; ++i) { const T a = od_abs(r[M::BIL[i]]); v = (a > v || a != a) ? a : v; }
+    for (int i = 0; i < M::NBIL; ++i) { const T a = od_abs(r[M::BIL[i]]); v = od_fmax(v, a); s += a; }
   }
-  return v;
+  return (s != s) ? s : v;
 }
 
 // CVXOPT sec. 8.2 step to the boundary of a second-order cone for lam + alpha*dlt
@@ -295,9 +297,10 @@ OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, boo
 // theta = [q2 - h*v1 ; q2 ; u ; friction ; h] and z0 = initialize_z!(q2) for the mechanical models
 // (RoboDojo.step! as called from src/dynamics.jl:82-88); v1 = (q2 - q1)/h.
 template <class M, class T> OD_HD void mech_setup(const T* q1, const T* q2, const T* u, const T* fric, T h, T* th, T* z) {
+  const T hinv = od_rcp(h);
 #pragma unroll
   for (int i = 0; i < M::NQ; ++i) {
-    const T v1 = (q2[i] - q1[i]) / h;
+    const T v1 = (q2[i] - q1[i]) * hinv;
     th[i] = q2[i] - h * v1;
     th[M::NQ + i] = q2[i];
   }
