@@ -61,6 +61,7 @@ template <class T> Opts<T> to_opts(const od_options& o) {
   r.undercut_inv = std::isinf(o.undercut) ? T(0) : (T)(1.0 / o.undercut);
   r.max_iter = o.max_iter;
   r.max_ls = o.max_ls;
+  r.coop = 0;               // set by the launchers that know the lane map (od_model_tu.inc)
   return r;
 }
 

@@ -27,6 +27,10 @@ namespace od {
 template <class T> struct Opts {
   T r_tol, kappa_eval, kappa_grad, eps_min, kappa_reg, gamma_reg, undercut_inv;
   int max_iter, max_ls;
+  // launch-side hint, not a solver option: when a wavefront carries ppw = 1, 2 or 4 problems, lanes
+  // 0..15 hold 16/ppw copies of each (LaneMap, od_vtable.h); `coop` = ppw lets the copies share out
+  // independent pieces of work and combine them across lanes.  0 = every lane does everything.
+  int coop;
 };
 
 enum : int { OD_ST_EVAL_OK = 1, OD_ST_GRAD_OK = 2, OD_ST_FACTOR_OK = 4 };
@@ -86,8 +90,64 @@ template <class M, int C, class T> OD_HD T soc_step_cone(const T* z, const T* D,
   else return a;
 }
 
+// ---- lane cooperation between the copies of one problem (Opts::coop) --------------------------------
+// Lanes 0..15 of a wavefront are one DPP row; the copies of a problem sit ppw lanes apart, so rotating
+// the row by ppw and 2*ppw reaches four of them.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int R> __device__ __forceinline__ double od_row_ror(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x120 + R, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x120 + R, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int R> __device__ __forceinline__ float od_row_ror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x120 + R, 0xF, 0xF, false));
+}
+template <class T> __device__ __forceinline__ T coop_min4(T v, int ppw) {
+  if (ppw == 4) { v = od_min(v, od_row_ror<4>(v)); v = od_min(v, od_row_ror<8>(v)); }
+  else if (ppw == 2) { v = od_min(v, od_row_ror<2>(v)); v = od_min(v, od_row_ror<4>(v)); }
+  else { v = od_min(v, od_row_ror<1>(v)); v = od_min(v, od_row_ror<2>(v)); }
+  return v;
+}
+__device__ __forceinline__ int coop_group(int ppw) { return (((int)threadIdx.x & 63) / ppw) & 3; }
+#else   // the host test build runs lanes one after the other: no cooperation
+template <class T> OD_HD T coop_min4(T v, int) { return v; }
+OD_HD int coop_group(int) { return 0; }
+#endif
+
+template <class M> constexpr bool soc_uniform() {
+  for (int c = 0; c < M::NSOC; ++c)
+    if (M::SOCOFF[c + 1] - M::SOCOFF[c] != M::SOCOFF[1] - M::SOCOFF[0]) return false;
+  return M::NSOC > 0;
+}
+template <class T> OD_HD T coop_pick(int g, T v0, T v1, T v2, T v3) {
+  const T lo = (g & 1) ? v1 : v0, hi = (g & 1) ? v3 : v2;
+  return (g & 2) ? hi : lo;
+}
+// The 2*NSOC cone steps (primal and dual variable of every cone) shared out over the four copies:
+// copy g takes steps g, g+4, ...; requires cones of one dimension.
+template <class M, class T> OD_HD T soc_step_coop(const T* z, const T* D, T tau, int ppw) {
+  constexpr int n = M::SOCOFF[1] - M::SOCOFF[0], NU = 2 * M::NSOC;
+  const int g = coop_group(ppw);
+  T a = T(1);
+#pragma unroll
+  for (int r0 = 0; r0 < NU; r0 += 4) {
+    T lam[n], dl[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      // step u = 2*cone + (0 primal | 1 dual); steps past the end repeat the last one (harmless under min)
+      auto idx = [](int u, int i_) constexpr { u = u < NU ? u : NU - 1; return ((u & 1) ? M::SOC2 : M::SOC1)[M::SOCOFF[u >> 1] + i_]; };
+      const int k0 = idx(r0, i), k1 = idx(r0 + 1, i), k2 = idx(r0 + 2, i), k3 = idx(r0 + 3, i);
+      lam[i] = coop_pick(g, z[k0], z[k1], z[k2], z[k3]);
+      dl[i] = -coop_pick(g, D[k0], D[k1], D[k2], D[k3]);
+    }
+    a = od_min(a, soc_step_one<n>(lam, dl, tau));
+  }
+  return coop_min4(a, ppw);
+}
+
 // largest alpha in (0,1] keeping z - alpha*D inside the cones (fractions tau_ort / tau_soc)
-template <class M, class T> OD_HD T step_length(const T* z, const T* D, T tau_ort, T tau_soc) {
+template <class M, class T> OD_HD T step_length(const T* z, const T* D, T tau_ort, T tau_soc, int coop) {
   T a = T(1);
   if constexpr (M::NORT > 0) {
     // min over the ratio tests tau*z_k/D_k (D_k > 0) kept as a fraction: one reciprocal at the end
@@ -101,7 +161,12 @@ template <class M, class T> OD_HD T step_length(const T* z, const T* D, T tau_or
     }
     a = num * od_rcp(den);
   }
-  if constexpr (M::NSOC > 0) a = soc_step_cone<M, 0>(z, D, tau_soc, a);
+  if constexpr (M::NSOC > 0) {
+    if constexpr (soc_uniform<M>()) {
+      if (coop) return od_min(a, soc_step_coop<M>(z, D, tau_soc, coop));
+    }
+    a = soc_step_cone<M, 0>(z, D, tau_soc, a);
+  }
   return a;
 }
 
@@ -225,7 +290,7 @@ OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, boo
     T D[M::NZ];
     M::solve(f, r, D);                                   // affine (predictor) direction
     if constexpr (CONES) {
-      const T aaff = step_length<M>(z, D, T(1), T(1));
+      const T aaff = step_length<M>(z, D, T(1), T(1), o.coop);
       T kap = centering_kappa<M>(z, D, aaff);
       kap = od_max(kap, o.kappa_eval * o.undercut_inv);
 #pragma unroll
@@ -239,7 +304,7 @@ OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, boo
     }
     const T vio = od_max(r_vio, k_vio);
     const T tau = T(1) - od_min(o.eps_min, vio * vio);
-    T alpha = step_length<M>(z, D, tau, od_min(tau, T(0.99)));
+    T alpha = step_length<M>(z, D, tau, od_min(tau, T(0.99)), o.coop);
     T zc[M::NZ];
     T r_c = T(0), k_c = T(0);
     for (int ls = 0; ls < o.max_ls; ++ls) {
