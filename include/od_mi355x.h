@@ -155,6 +155,12 @@ int od_ip_solve(od_handle h, long B, const void* z0, const void* theta, void* z,
 int od_rocket(od_handle h, long B, int project, const void* x, const void* u, void* y, void* dx,
               void* du, void* uproj, int* status);
 
+/* soc_projection / soc_projection_gradient (src/models/rocket/dynamics.jl:168-214) on an OD_ROCKET_DYNAMICS
+ * handle: Euclidean projection of u (3 per problem) onto the thrust cone {|u_1:2| <= u_3 <= u_max} by the
+ * interior-point solve the reference uses (z0 and options of :169-175).  uproj: 3; duproj: 3 x 3 col-major
+ * d uproj / d u (NULL = diff_sol false); status bits 16 / 32 = state / gradient converged. */
+int od_soc_project(od_handle h, long B, const void* u, void* uproj, void* duproj, int* status);
+
 /* iLQR.rollout / forward pass over f_rocket (project = 0) or f_rocket_proj (project = 1), time recursion on the
  * device (examples/rocket.jl:29-41,118).  nalpha = 0: open loop, controls ubar (3 per knot, T*B knots), B
  * trajectories.  nalpha > 0: closed loop u = ubar + alpha k + K (x - xbar) for nalpha step sizes (candidate

@@ -3,7 +3,8 @@
 # points are exercised through ctypes by tests/.  See INTEGRATION.md.
 module OptimizationDynamicsMI355X
 
-export ImplicitDynamicsMI355X, f, fx, fu, state_to_configuration, od_step_grad!, od_rollout!
+export ImplicitDynamicsMI355X, f, fx, fu, state_to_configuration, od_step_grad!, od_rollout!,
+       RocketInfoMI355X, od_rocket!, od_soc_project!
 
 const LIB = get(ENV, "OD_MI355X_LIB", joinpath(@__DIR__, "..", "optimization_dynamics_amd", "libod_mi355x.so"))
 
@@ -92,6 +93,31 @@ function od_rollout!(m::ImplicitDynamicsMI355X, B, T, x1, U, X, A, Bm)
     check(ccall((:od_set_layout, LIB), Cint, (Ptr{Cvoid}, Cint), m.h, 1))
     check(ccall((:od_rollout, LIB), Cint, (Ptr{Cvoid}, Clong, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}),
                 m.h, B, T, pointer(x1), pointer(U), pointer(X), pointer(A), pointer(Bm), C_NULL, C_NULL))
+end
+
+# rocket (src/models/rocket/dynamics.jl): one OD_ROCKET_DYNAMICS handle plays ip_dyn and ip_proj
+mutable struct RocketInfoMI355X
+    h::Ptr{Cvoid}
+end
+function RocketInfoMI355X(u_max::Float64, h::Float64)
+    hd = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:od_create, LIB), Cint, (Cint, Cint, Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}), MODEL_IDS[:rocket], 0, C_NULL, h, hd))
+    check(ccall((:od_set_u_max, LIB), Cint, (Ptr{Cvoid}, Cdouble), hd[], u_max))
+    r = RocketInfoMI355X(hd[])
+    finalizer(x -> ccall((:od_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), r)
+    return r
+end
+"batched soc_projection / soc_projection_gradient (dynamics.jl:168-214) on device arrays: U 3×B, UP 3×B, DP 9×B"
+function od_soc_project!(r::RocketInfoMI355X, B, U, UP, DP)
+    check(ccall((:od_set_layout, LIB), Cint, (Ptr{Cvoid}, Cint), r.h, 1))
+    check(ccall((:od_soc_project, LIB), Cint, (Ptr{Cvoid}, Clong, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}),
+                r.h, B, pointer(U), pointer(UP), pointer(DP), C_NULL))
+end
+"batched f_rocket(_proj) + fx + fu (dynamics.jl:101-164, 215-268): X 12×B, U 3×B -> Y 12×B, DX 144×B, DU 36×B"
+function od_rocket!(r::RocketInfoMI355X, B, project::Bool, X, U, Y, DX, DU)
+    check(ccall((:od_set_layout, LIB), Cint, (Ptr{Cvoid}, Cint), r.h, 1))
+    check(ccall((:od_rocket, LIB), Cint, (Ptr{Cvoid}, Clong, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}),
+                r.h, B, project ? 1 : 0, pointer(X), pointer(U), pointer(Y), pointer(DX), pointer(DU), C_NULL, C_NULL))
 end
 
 end # module

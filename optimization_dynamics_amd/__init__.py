@@ -13,4 +13,4 @@ from .ls import LeastSquares, update_  # noqa: F401
 from .models import (acrobot_impact, acrobot_nominal, cartpole_friction, cartpole_frictionless,  # noqa: F401
                      hopper, planarpush, rocket)
 from .rocket import (RocketDynamics, RocketInfo, f_rocket, f_rocket_proj, fu_rocket, fu_rocket_proj, fx_rocket,  # noqa: F401
-                     fx_rocket_proj, soc_projection)
+                     fx_rocket_proj, soc_projection, soc_projection_gradient)

@@ -64,6 +64,7 @@ SIGNATURES = {
     "od_raw_grad_dims": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "od_ip_solve": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _VP, _IP, _IP]),
     "od_rocket": (C.c_int, [_VP, C.c_long, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _IP]),
+    "od_soc_project": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _IP]),
     "od_rocket_rollout": (C.c_int, [_VP, C.c_long, C.c_int, C.c_int, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _IP]),
     "od_f_host": (C.c_int, [_VP, _VP, _VP, _VP]),
     "od_fx_host": (C.c_int, [_VP, _VP, _VP, _VP]),

@@ -390,6 +390,20 @@ template <class T> static RocketArgs<T> rocket_args(od_handle h, long B, int pro
   return a;
 }
 
+template <class T> static int soc_project_impl(od_handle h, long B, const void* u, void* uproj, void* duproj, int* status) {
+  const int L = h->layout;
+  RocketArgs<T> a = rocket_args<T>(h, B, 1, duproj ? 1 : 0);
+  a.u = mkcview<T>(u, 3, B, L);
+  a.uproj = mkview<T>(uproj, 3, B, L);
+  a.du = mkview<T>(duproj, 9, B, L);
+  a.status = mkview<int>(status, 1, B, L);
+  hipError_t e;
+  if constexpr (sizeof(T) == 8) e = launch_soc_project64(a, ppw_of(h, B), h->stream);
+  else e = launch_soc_project32(a, ppw_of(h, B), h->stream);
+  if (e != hipSuccess) return fail(OD_ERR_HIP, std::string("od_soc_project launch: ") + hipGetErrorString(e));
+  return OD_OK;
+}
+
 template <class T> static int rocket_rollout_impl(od_handle h, long B, int Tn, int nalpha, const void* alphas, int project,
                                                   const void* x1, const void* xbar, const void* ubar, const void* K,
                                                   const void* kff, void* X, void* U, int* status) {
@@ -741,6 +755,15 @@ int od_rocket(od_handle h, long B, int project, const void* x, const void* u, vo
   if (!x || !u) return fail(OD_ERR_INVALID, "od_rocket: null input");
   if (h->dtype == OD_F64) return rocket_impl<double>(h, B, project, x, u, y, dx, du, uproj, status);
   return rocket_impl<float>(h, B, project, x, u, y, dx, du, uproj, status);
+}
+
+int od_soc_project(od_handle h, long B, const void* u, void* uproj, void* duproj, int* status) {
+  if (!h) return fail(OD_ERR_INVALID, "od_soc_project: null handle");
+  if (h->vt->id != OD_ROCKET_DYNAMICS) return fail(OD_ERR_UNSUPPORTED, "od_soc_project: needs an OD_ROCKET_DYNAMICS handle");
+  if (B <= 0) return OD_OK;
+  if (!u) return fail(OD_ERR_INVALID, "od_soc_project: null input");
+  if (h->dtype == OD_F64) return soc_project_impl<double>(h, B, u, uproj, duproj, status);
+  return soc_project_impl<float>(h, B, u, uproj, duproj, status);
 }
 
 // ---- host scalar path ------------------------------------------------------------------------

@@ -414,6 +414,31 @@ OD_HD void rocket_knot(const RocketArgs<T>& a, long b, const T* x, T* u, T* y) {
   if (a.status.ok()) a.status.at(0, b) = st;
 }
 
+// soc_projection / soc_projection_gradient alone (dynamics.jl:168-214): u -> uproj (3), d uproj / d u (3 x 3
+// col-major, written to `du`); x, y, dx unused.  status bits 16 / 32 as in od_rocket.
+template <class MP, class T> OD_HD void unit_soc_project(const RocketArgs<T>& a, long b) {
+  T zp[MP::NZ], thp[MP::NTH], dproj[9];
+#pragma unroll
+  for (int i = 0; i < MP::NZ; ++i) zp[i] = T(MP::ZI_VAL[i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) thp[i] = a.u.at(i, b);
+  thp[3] = a.u_max;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) dproj[i] = T(0);
+  ProjSink<T> ps{dproj};
+  int itp[2];
+  const int sp_ = ip_step_grad<MP>(a.opts_proj, thp, zp, true, a.want_grad != 0, ps, itp);
+  if (a.uproj.ok()) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.uproj.at(i, b) = zp[i];
+  }
+  if (a.want_grad && a.du.ok()) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a.du.at(i, b) = dproj[i];
+  }
+  if (a.status.ok()) a.status.at(0, b) = (sp_ & 3) << 4;
+}
+
 template <class MD, class MP, class T> OD_HD void unit_rocket(const RocketArgs<T>& a, long b) {
   T x[12], u[3], y[12];
 #pragma unroll

@@ -35,6 +35,8 @@ const ModelVT* vt_hopper();
 
 hipError_t launch_rocket64(const RocketArgs<double>&, int ppw, hipStream_t);
 hipError_t launch_rocket32(const RocketArgs<float>&, int ppw, hipStream_t);
+hipError_t launch_soc_project64(const RocketArgs<double>&, int ppw, hipStream_t);
+hipError_t launch_soc_project32(const RocketArgs<float>&, int ppw, hipStream_t);
 hipError_t launch_rocket_rollout64(const RocketRolloutArgs<double>&, int ppw, hipStream_t);
 hipError_t launch_rocket_rollout32(const RocketRolloutArgs<float>&, int ppw, hipStream_t);
 

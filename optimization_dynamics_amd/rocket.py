@@ -71,6 +71,19 @@ class RocketInfo:
             DU = DU.view(3, 12, B).transpose(0, 1)
         return Y, DX, DU, UP, st
 
+    def project(self, U, grads=True):
+        """batched soc_projection(_gradient): U (3, B) -> (uproj (3, B), duproj (3, 3, B) or None, status (B,))"""
+        self._use_current_stream()
+        U = U.to(device=self.device, dtype=self.dtype).contiguous()
+        B = U.shape[1]
+        UP = torch.empty(3, B, dtype=self.dtype, device=self.device)
+        DP = torch.zeros(9, B, dtype=self.dtype, device=self.device) if grads else None
+        st = torch.zeros(B, dtype=torch.int32, device=self.device)
+        self.lib.check(self.lib.cdll.od_soc_project(self._h, B, _ptr(U), _ptr(UP), _ptr(DP) if grads else None, _ptr(st)))
+        if grads:
+            DP = DP.view(3, 3, B).transpose(0, 1)       # col-major 3 x 3 per problem: element (i, c) at row i + 3c
+        return UP, DP, st
+
 
 def _rocket_rollout(info, x1, U, project, policy=None):
     """time recursion on the device.  x1 (12, B), U = ubar (3, T, B).
@@ -174,7 +187,11 @@ def fu_rocket_proj(du, info: RocketInfo, x, u, w=None):
 def soc_projection(x, info: RocketInfo):
     """dynamics.jl:168-186: Euclidean projection of x onto {|u_1:2| <= u_3, 0 <= u_3 <= u_max}
     (interior-point solution at kappa_tol = 1e-4)."""
-    X = torch.zeros(12, 1, dtype=torch.float64)
     U = torch.tensor(np.asarray(x, dtype=np.float64)).reshape(3, 1)
-    _, _, _, UP, _ = info.solve(X, U, project=True, grads=False)
-    return UP[:, 0].double().cpu().numpy()
+    return info.project(U, grads=False)[0][:, 0].double().cpu().numpy()
+
+
+def soc_projection_gradient(x, info: RocketInfo):
+    """dynamics.jl:191-211: d soc_projection(x) / d x (3 x 3), the implicit gradient of the same solve."""
+    U = torch.tensor(np.asarray(x, dtype=np.float64)).reshape(3, 1)
+    return info.project(U, grads=True)[1][:, :, 0].double().cpu().numpy()

@@ -244,3 +244,46 @@ def check_scalar_callbacks(oracle, lib, device, name):
         assert np.abs(du - duo).max() < 5e-3 * max(1, np.abs(duo).max())
     q = dyn.state_to_configuration([X[:, 0], np.r_[X[nq:, 0], X[:nq, 0]]])
     assert len(q) == 3 and np.all(q[0] == X[:nq, 0]) and np.all(q[1] == X[nq:, 0]) and np.all(q[2] == X[:nq, 0])
+
+
+def check_soc_projection(oracle, lib, device, B=96):
+    """od_soc_project (soc_projection / soc_projection_gradient, dynamics.jl:168-214) against the oracle and
+    against the properties of a Euclidean projection onto {|u_1:2| <= u_3 <= u_max}."""
+    rng = np.random.default_rng(7)
+    U = np.stack([rng.normal(0, 4, B), rng.normal(0, 4, B), rng.uniform(-4, 18, B)])
+    U[:, 0] = [0.3, -0.2, 5.0]            # strictly inside: projection = identity, gradient = I
+    U[:, 1] = [0.0, 0.0, 20.0]            # above u_max on the axis
+    U[:, 2] = [3.0, 4.0, -10.0]           # in the polar cone: projects to the apex
+    info = rk.RocketInfo(models.rocket, 12.5, 0.05, device=device, lib=lib)
+    UP, DP, st = info.project(torch.tensor(U), grads=True)
+    UP, DP, st = UP.cpu().numpy(), DP.cpu().numpy(), st.cpu().numpy()
+    assert ((st & 0x30) == 0x30).all()
+    # feasibility (the reference's own check, examples/rocket.jl:151) at kappa_tol = 1e-4 accuracy
+    assert (np.hypot(UP[0], UP[1]) <= UP[2] + 2e-2).all() and (UP[2] <= 12.5 + 1e-3).all() and (UP[2] >= -1e-3).all()
+    assert np.abs(UP[:, 0] - U[:, 0]).max() < 2e-3 and np.abs(DP[:, :, 0] - np.eye(3)).max() < 2e-2
+    assert abs(UP[2, 1] - 12.5) < 2e-3 and np.abs(UP[:2, 1]).max() < 1e-3
+    assert np.abs(UP[:, 2]).max() < 5e-2
+    ntight = 0
+    for b in range(B):
+        s, z, dz, it = oracle.soc_projection(12.5, U[:, b], True)
+        eu = np.abs(UP[:, b] - z[:3]).max() / max(1.0, np.abs(z[:3]).max())
+        # eps_min = 0 makes the accepted step lengths a matter of rounding noise (see check_rocket):
+        # same path -> tight, otherwise both are kappa_tol-accurate solutions
+        if eu < 1e-7:
+            ntight += 1
+            assert np.abs(DP[:, :, b] - dz[:3, :3]).max() < GRAD_TOL * max(1.0, np.abs(dz[:3, :3]).max())
+        else:
+            assert eu < 2e-4
+    assert ntight >= 0.7 * B
+    # scalar mirrors of the reference functions
+    up0 = rk.soc_projection(U[:, 5], info)
+    dp0 = rk.soc_projection_gradient(U[:, 5], info)
+    assert np.allclose(up0, UP[:, 5]) and np.allclose(dp0, DP[:, :, 5])
+    # gradient against central differences of the projection itself
+    e = 1e-5
+    J = np.zeros((3, 3, B))
+    for j in range(3):
+        Up, Um = U.copy(), U.copy(); Up[j] += e; Um[j] -= e
+        J[:, j] = (info.project(torch.tensor(Up), grads=False)[0].cpu().numpy()
+                   - info.project(torch.tensor(Um), grads=False)[0].cpu().numpy()) / (2 * e)
+    assert np.median(np.abs(J - DP).reshape(9, B).max(0)) < 5e-2

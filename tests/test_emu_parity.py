@@ -61,6 +61,10 @@ def test_rocket_f32(oracle, emu_lib):
     P.check_rocket(oracle, emu_lib, "cpu", 16, dtype=torch.float32)
 
 
+def test_soc_projection(oracle, emu_lib):
+    P.check_soc_projection(oracle, emu_lib, "cpu", 48)
+
+
 @pytest.mark.parametrize("name", ["acrobot_impact", "cartpole_friction"])
 def test_reference_signature_callbacks(oracle, emu_lib, name):
     P.check_scalar_callbacks(oracle, emu_lib, "cpu", name)
