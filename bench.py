@@ -193,7 +193,7 @@ def main():
                          "achieved": ach_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / FP64_PEAK_TFLOPS,
                          # HBM bytes per od_rollout from the rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE over both
                          # kernels, profiles/r1_pmc_summary.txt); only valid for the default workload
-                         "traffic": (458.2e6 if (B == 4096 and T == 100 and not args.gather) else None),
+                         "traffic": (469.4e6 if (B == 4096 and T == 100 and not args.gather) else None),
                          "traffic_note": "bytes per launch pair, measured offline with rocprofv3 --pmc (profiles/); algorithmic = %d" % (algorithmic_bytes_per_unit() * units_per_rank),
                          "kernel": "od_rollout = k_rollout_state<Model_hopper,double> (99 %) + k_grad_knots<Model_hopper,double>", "kernel_ms": kernel_ms,
                          "algorithmic_flops_per_unit": F, "mean_iterations_to_kappa_eval": it_eval, "max_iterations": it_max,

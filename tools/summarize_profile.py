@@ -1,0 +1,45 @@
+"""Condense gpurun_out/prof_<tag> (written by tools/profile_round.sh on the GPU box) into profiles/.
+usage: python tools/summarize_profile.py r1"""
+import collections, csv, json, os, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, tag + "_bench.json"))
+
+
+def per_kernel(d):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(os.path.join(src, d, "p_counter_collection.csv"))):
+        k = r["Kernel_Name"]
+        k = "k_rollout_state" if "k_rollout_state" in k else "k_grad_knots" if "k_grad_knots" in k else None
+        if k:
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}, \
+           {k: len(next(iter(cs.values()))) for k, cs in acc.items()}
+
+
+out = ["# round %s -- PMC summaries for `python bench.py --steps 3 --warmup 1 --no-cpu-baseline` (hopper T=100 batch=4096, MI355X)" % tag,
+       "# collected with tools/profile_round.sh: separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*), each with --kernel-trace only"]
+tot = 0.0
+for d, c, mult in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SIZE", 1.0)):
+    m, n = per_kernel(d)
+    for k in ("k_rollout_state", "k_grad_knots"):
+        out.append("od::%s %s per dispatch [KB]: mean %.1f  (n=%d)" % (k, c, m[k][c], n[k]))
+        tot += mult * m[k][c] * 1024
+m, n = per_kernel("pmc_sq")
+for k in ("k_rollout_state", "k_grad_knots"):
+    out.append("%s SQ counters per dispatch (SQ_*_CYCLES in quad-cycles): %s" % (k, json.dumps({c: int(v) for c, v in sorted(m[k].items())})))
+out.append("HBM bytes per od_rollout (2*FETCH_SIZE + WRITE_SIZE, both kernels; FETCH_SIZE counts half of wide coalesced reads on gfx950): %.1f MB" % (tot / 1e6))
+s = m["k_rollout_state"]
+out.append("k_rollout_state: %d wavefronts, %.2f M VALU instructions per wavefront, %.2f quad-cycles per VALU instruction, VALU active %.0f %% of wave cycles, waiting on memory %.0f %%, issue stalls %.1f %%"
+           % (s["SQ_WAVES"], s["SQ_INSTS_VALU"] / s["SQ_WAVES"] / 1e6, s["SQ_WAVE_CYCLES"] / s["SQ_INSTS_VALU"],
+              100 * s["SQ_ACTIVE_INST_VALU"] / s["SQ_WAVE_CYCLES"], 100 * s["SQ_WAIT_ANY"] / s["SQ_WAVE_CYCLES"],
+              100 * s["SQ_WAIT_INST_ANY"] / s["SQ_WAVE_CYCLES"]))
+notes = os.path.join(dst, tag + "_pmc_notes.txt")
+if os.path.exists(notes):
+    out.append("")
+    out.append(open(notes).read().rstrip())
+open(os.path.join(dst, tag + "_pmc_summary.txt"), "w").write("\n".join(out) + "\n")
+print("\n".join(out))
