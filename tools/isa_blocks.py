@@ -6,7 +6,7 @@ model, kern = sys.argv[1], sys.argv[2]
 minb = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 src = os.path.join(ROOT, "optimization_dynamics_amd", "csrc", "od_model_%s.hip" % model)
 out = "/tmp/isa_%s.s" % model
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src] + os.environ.get("EXTRA", "").split(),
                       stderr=subprocess.DEVNULL)
 txt = open(out).read()
 m = re.search(r"^(_ZN2od\d+%s\w+):" % kern, txt, re.M)
