@@ -14,8 +14,10 @@ namespace od {
 // offset per element: those offsets (dozens per view) otherwise live in SGPRs across the whole
 // interior-point loop and are spilled to VGPR lanes (v_writelane/v_readlane)
 #define OD_OPAQUE_PTR(p) asm volatile("" : "+v"(p))
+#define OD_GLOBAL_PTR(T, p) ((T __attribute__((address_space(1)))*)(p))
 #else
 #define OD_OPAQUE_PTR(p) (void)0
+#define OD_GLOBAL_PTR(T, p) (p)
 #endif
 
 template <class T> struct View {
@@ -27,8 +29,9 @@ template <class T> struct View {
   struct Cursor {
     T* q;
     long se;
-    OD_HD void put(T v) { *q = v; q += se; OD_OPAQUE_PTR(q); }
-    OD_HD T get() { const T v = *q; q += se; OD_OPAQUE_PTR(q); return v; }
+    // (the opaque pointer has lost its address space: say "global" again, or the accesses become FLAT)
+    OD_HD void put(T v) { *OD_GLOBAL_PTR(T, q) = v; q += se; OD_OPAQUE_PTR(q); }
+    OD_HD T get() { const T v = *OD_GLOBAL_PTR(T, q); q += se; OD_OPAQUE_PTR(q); return v; }
     OD_HD void skip(int n) { q += n * se; OD_OPAQUE_PTR(q); }
   };
   OD_HD Cursor cursor(long b) const { Cursor c{p + b * sb, se}; OD_OPAQUE_PTR(c.q); return c; }
@@ -143,12 +146,22 @@ template <class M, class T> OD_HD void unit_rollout_state(const RolloutArgs<T>& 
 #pragma unroll
     for (int i = 0; i < n; ++i) ra.x0.at(i, b) = x[i];
   }
+  // the control of knot t+1 is requested before knot t is solved: its latency (and the drain of knot
+  // t-1's stores that an in-order wait would include) stays off the recursion's critical path
+  T un[M::NU > 0 ? M::NU : 1];
+  {
+    auto c = a.u.cursor(b);
+#pragma unroll
+    for (int i = 0; i < M::NU; ++i) un[i] = c.get();
+  }
   for (int t = 0; t < ra.Tn; ++t) {
     const long k = (long)t * a.B + b;
-    {
-      auto c = a.u.cursor(k);
 #pragma unroll
-      for (int i = 0; i < M::NU; ++i) u[i] = c.get();
+    for (int i = 0; i < M::NU; ++i) u[i] = un[i];
+    if (t + 1 < ra.Tn) {
+      auto c = a.u.cursor(k + a.B);
+#pragma unroll
+      for (int i = 0; i < M::NU; ++i) un[i] = c.get();
     }
     knot_state<M, T>(a, k, x, u, q3);
 #pragma unroll
