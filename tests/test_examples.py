@@ -1,0 +1,56 @@
+"""The reference's example problems driven end to end through the engine (examples/*.py mirror examples/*.jl):
+augmented-Lagrangian iLQR (optimization_dynamics_amd.ilqr_al) around od_step / od_step_grad / od_ilqr_backward.
+IterativeLQR.jl is un-vendored, so these are property tests: constraints met to the examples' con_tol, cost reduced,
+the gait periodic and travelling."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+
+
+def _check_gait(solver, X, U, x1):
+    viol = solver.violation(X, U)
+    assert viol.max().item() <= 1.0e-3                                     # con_tol of examples/hopper.jl:279
+    q1_first, q2_first = U[2:6, 0], U[6:10, 0]                             # optimised initial configurations
+    th = X[8:, -1]
+    assert (th[:4] - q1_first).abs().max().item() < 1e-12 and (th[4:] - q2_first).abs().max().item() < 1e-12
+    xT = X[:8, -1]
+    assert ((xT[0] - th[0]) >= 0.5 - 1e-3).all() and ((xT[4] - th[4]) >= 0.5 - 1e-3).all()        # travels half a metre
+    assert (xT[1:4] - th[1:4]).abs().max().item() < 1e-3 and (xT[5:8] - th[5:8]).abs().max().item() < 1e-3   # periodic
+    assert (U[:2].abs() <= 10.0 + 1e-3).all()                              # control limits
+    # every knot of the solution is a converged step of the engine: re-rolling the controls reproduces the states
+    Xr = solver.rollout(x1, U)
+    assert (Xr - X).abs().max().item() < 1e-9
+
+
+def test_hopper_gait_cpu(emu_lib):
+    import hopper_gait
+    solver, x1, U0 = hopper_gait.problem(1, device="cpu", lib=emu_lib)
+    J0 = solver.objective(solver.rollout(x1, U0), U0)
+    X, U = solver.solve(x1, U0)
+    _check_gait(solver, X, U, x1)
+    assert torch.isfinite(solver.objective(X, U)).all() and J0.isfinite().all()
+
+
+@pytest.mark.gpu
+def test_hopper_gait_gpu(gpu_lib):
+    import hopper_gait
+    solver, x1, U0 = hopper_gait.problem(3, device="cuda:0", lib=gpu_lib)
+    U0[1, :, 1] *= 1.05                                                     # three slightly different starts
+    U0[1, :, 2] *= 0.95
+    X, U = solver.solve(x1, U0)
+    _check_gait(solver, X, U, x1)
+
+
+@pytest.mark.gpu
+def test_acrobot_swing_up_gpu(gpu_lib):
+    import acrobot
+    solver, x1, U0, xT = acrobot.problem(1, device="cuda:0", lib=gpu_lib)
+    X, U = solver.solve(x1, U0)
+    assert (X[:, -1] - xT[:, None]).abs().max().item() <= 1.0e-3            # con_tol of examples/acrobot.jl:104
+    assert (X[1].abs() <= np.pi / 2 + 1e-3).all() and (X[3].abs() <= np.pi / 2 + 1e-3).all()     # joint limits held throughout
+    assert solver.objective(X, U).item() < 500.0
