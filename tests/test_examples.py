@@ -54,3 +54,24 @@ def test_acrobot_swing_up_gpu(gpu_lib):
     assert (X[:, -1] - xT[:, None]).abs().max().item() <= 1.0e-3            # con_tol of examples/acrobot.jl:104
     assert (X[1].abs() <= np.pi / 2 + 1e-3).all() and (X[3].abs() <= np.pi / 2 + 1e-3).all()     # joint limits held throughout
     assert solver.objective(X, U).item() < 500.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("GB", [False, True])
+def test_planar_push_rotate_gpu(gpu_lib, GB):
+    """examples/planar_push.jl, MODE = :rotate, with the implicit-function gradient and with the gradient bundle"""
+    import planar_push
+    solver, x1, U0, xT = planar_push.problem("rotate", 1, GB=GB, device="cuda:0", lib=gpu_lib)
+    X, U = solver.solve(x1, U0)
+    assert solver.violation(X, U).max().item() <= 5.0e-3                    # con_tol of examples/planar_push.jl:124
+    assert (X[5:8, -1] - xT[5:8, None]).abs().max().item() <= 5.0e-3        # block at (0.5, 0.5, pi/2)
+    assert (U.abs() <= 5.0 + 5e-3).all()
+
+
+@pytest.mark.gpu
+def test_cartpole_frictionless_swing_up_gpu(gpu_lib):
+    import cartpole
+    solver, x1, U0, xT = cartpole.problem("frictionless", 2, device="cuda:0", lib=gpu_lib)
+    U0[:, 0, 1] = -1.4
+    X, U = solver.solve(x1, U0)
+    assert (X[:, -1] - xT[:, None]).abs().max().item() <= 5.0e-3            # con_tol of examples/cartpole.jl:92
