@@ -67,7 +67,7 @@ class ImplicitStage:
 
 class Solver:
     def __init__(self, stages, costs, cons, n, m, *, im, alpha_min=1.0e-5, obj_tol=1.0e-3, grad_tol=1.0e-3, max_iter=10,
-                 max_al_iter=15, con_tol=1.0e-3, rho_init=1.0, rho_scale=10.0, reg=1.0e-6, c1=1.0e-4, verbose=False):
+                 max_al_iter=15, con_tol=1.0e-3, rho_init=1.0, rho_scale=10.0, rho_max=1.0e8, reg=1.0e-6, c1=1.0e-4, verbose=False):
         """stages: T-1 dynamics objects (step / step_grad on (n, P), (m, P)); costs: T Cost (last terminal);
         cons: T Constraint (fn None = unconstrained); im: any ImplicitDynamics handle (device, stream and
         the Riccati kernel are reached through it)."""
@@ -76,7 +76,7 @@ class Solver:
         self.T, self.n, self.m, self.im = len(stages), n, m, im
         self.dev = im.device
         self.o = dict(alpha_min=alpha_min, obj_tol=obj_tol, grad_tol=grad_tol, max_iter=max_iter, max_al_iter=max_al_iter,
-                      con_tol=con_tol, rho_init=rho_init, rho_scale=rho_scale, reg=reg, c1=c1, verbose=verbose)
+                      con_tol=con_tol, rho_init=rho_init, rho_scale=rho_scale, rho_max=rho_max, reg=reg, c1=c1, verbose=verbose)
         na = 1
         while 2.0 ** -(na - 1) > alpha_min and na < 18:
             na += 1
@@ -304,7 +304,7 @@ class Solver:
                     idx = self.cons[t].idx_ineq
                     if idx:
                         lam[t][:, idx] = lam[t][:, idx].clamp_min(0.0)
-            rho *= o["rho_scale"]
+            rho = min(rho * o["rho_scale"], o["rho_max"])
         self.X, self.U, self.lam, self.rho = X, U, lam, rho
         return X, U
 
