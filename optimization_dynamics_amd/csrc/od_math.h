@@ -14,6 +14,8 @@
 
 // floor for static pivots on orthant slack variables (strictly positive, may underflow at convergence)
 #define OD_PIVOT_FLOOR 1e-12
+// largest dense tail that uses the branchy / guarded pivoting code (od_lu_factor)
+#define OD_LU_BRANCHY_MAX 8
 
 namespace od {
 
@@ -115,6 +117,13 @@ OD_HD double od_rsqrt(double x) { return 1.0 / sqrt(x); }
 OD_HD float od_rsqrt(float x) { return 1.0f / sqrtf(x); }
 #endif
 
+// true if the predicate holds in any active lane of the wavefront (a scalar branch on the device)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ bool od_any_lane(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0; }
+#else
+inline bool od_any_lane(bool pred) { return pred; }
+#endif
+
 template <class T> OD_HD T od_min(T a, T b) { return a < b ? a : b; }
 template <class T> OD_HD T od_max(T a, T b) { return a > b ? a : b; }
 // IEEE maxNum (one instruction on the device; a NaN operand is dropped)
@@ -151,8 +160,14 @@ template <class T, int N> OD_HD bool od_lu_factor(T* A, int* piv) {
     piv[k] = p;
     ok = ok && (best > T(0));
     // exchange rows k and p of the ACTIVE part only (columns >= k); the multipliers already stored
-    // in columns < k stay with their physical rows, and od_lu_solve replays the exchanges in order
-    if (p != k) {
+    // in columns < k stay with their physical rows, and od_lu_solve replays the exchanges in order.
+    // Small tails skip an exchange no lane of the wavefront needs (a scalar branch); for the large ones
+    // (planar push, 14 x 14, partly in scratch) the branch-free form is both faster and -- measured -- the
+    // only one hipcc 7.2 compiles reliably: with either kind of branch here, a fraction of the planar-push
+    // solves stopped converging depending on unrelated source details (a printf made them converge).
+    bool exchange = true;
+    if constexpr (N <= OD_LU_BRANCHY_MAX) exchange = od_any_lane(p != k);
+    if (exchange) {
 #pragma unroll
       for (int i = k + 1; i < N; ++i) {
         const bool sw = (p == i);
@@ -165,9 +180,11 @@ template <class T, int N> OD_HD bool od_lu_factor(T* A, int* piv) {
       }
     }
     // a column that vanished entirely (a cone variable stepped exactly onto its boundary: tau rounds to
-    // 1 once the violation is below 1e-8) makes the system singular; its unknown is dropped (x_k = 0)
-    // so that the outputs stay finite, and the caller reports the knot through FACTOR_OK
-    const T inv = best > T(0) ? od_rcp(A[k + N * k]) : T(0);
+    // 1 once the violation is below 1e-8) makes the system singular; in the small tails its unknown is
+    // dropped (x_k = 0) so that the outputs stay finite; the caller reports the knot through FACTOR_OK
+    T inv;
+    if constexpr (N > OD_LU_BRANCHY_MAX) inv = od_rcp(A[k + N * k]);
+    else inv = best > T(0) ? od_rcp(A[k + N * k]) : T(0);
     A[k + N * k] = inv;                       // the diagonal holds 1/u_kk
 #pragma unroll
     for (int i = k + 1; i < N; ++i) A[i + N * k] *= inv;
