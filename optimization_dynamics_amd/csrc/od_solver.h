@@ -228,13 +228,58 @@ OD_HD bool eval_factor(const T* z, const T* th, const T* pre, const T* tr, T reg
   return M::factor(a, f);
 }
 
+// One predictor-corrector iteration at z (r = r(z; 0), r_vio / k_vio its violations): factor, affine
+// direction, centering, corrector direction, step length, backtracking line search.  Shared by the
+// lockstep loop below and the decoupled rollout (od_units.h) so that both do identical arithmetic.
+template <class M, class T, class F>
+OD_HD void ip_iteration(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z, T* r, T& r_vio, T& k_vio, T& reg_prev,
+                        int& status, int it, F& f) {
+  constexpr bool CONES = (M::NORT + M::NSOC) > 0;
+  const T reg = (k_vio < o.kappa_reg) ? k_vio * o.gamma_reg : T(0);
+  reg_prev = reg;
+  if (!eval_factor<M>(z, th, pre, tr, reg, f)) status &= ~OD_ST_FACTOR_OK;
+  T D[M::NZ];
+  M::solve(f, r, D);                                   // affine (predictor) direction
+  if constexpr (CONES) {
+    const T aaff = step_length<M>(z, D, T(1), T(1), o.coop);
+    T kap = centering_kappa<M>(z, D, aaff);
+    kap = od_max(kap, o.kappa_eval * o.undercut_inv);
+#pragma unroll
+    for (int i = 0; i < M::NKROWS; ++i) r[M::KROWS[i]] -= kap;    // r(z; kappa) from r(z; 0)
+    if constexpr (M::NORT > 0) {
+#pragma unroll
+      for (int i = 0; i < M::NORT; ++i) r[M::ORTR[i]] += D[M::ORT1[i]] * D[M::ORT2[i]];
+    }
+    if constexpr (M::NSOC > 0) correction_cone<M, 0>(r, D);
+    M::solve(f, r, D);                                 // corrector direction, factors reused
+  }
+  const T vio = od_max(r_vio, k_vio);
+  const T tau = T(1) - od_min(o.eps_min, vio * vio);
+  T alpha = step_length<M>(z, D, tau, od_min(tau, T(0.99)), o.coop);
+  T zc[M::NZ];
+  T r_c = T(0), k_c = T(0);
+  for (int ls = 0; ls < o.max_ls; ++ls) {
+#pragma unroll
+    for (int i = 0; i < M::NZ; ++i) zc[i] = z[i] - alpha * D[i];
+    M::eval_r(zc, th, pre, tr, r);
+    r_c = viol_eq<M>(r);
+    k_c = viol_bil<M>(r);
+    if (r_c <= r_vio || k_c <= k_vio) break;
+    alpha *= T(0.5);
+  }
+#pragma unroll
+  for (int i = 0; i < M::NZ; ++i) z[i] = zc[i];
+  r_vio = r_c;
+  k_vio = k_c;
+  OD_TRACE_IT("dev it %d alpha %.17g r_vio %.6e k_vio %.6e\n", it + 1, (double)alpha, (double)r_vio, (double)k_vio);
+}
+
 // Sink concept:  void grad(int i /*row in ZQ*/, int c /*grad column*/, T v)
 //
 // z: in = initial guess, out = iterate at (r_tol, kappa_eval) convergence (or the last iterate).
 // Returns status bits; iters[0] = iterations to kappa_eval, iters[1] = iterations to kappa_grad.
 template <class M, class T, class Sink, class F>
 OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, bool want_grad, Sink& sink, int* iters, F& f) {
-  constexpr bool CONES = (M::NORT + M::NSOC) > 0;
   // state snapshot at (r_tol, kappa_eval): the whole z for raw solves, only the next configuration otherwise
   constexpr int NSNAP = Sink::FULL_STATE ? M::NZ : M::NZQ;
   T r[M::NZ], zs[NSNAP], pre[M::NPRE], tr[M::NTR];
@@ -284,43 +329,7 @@ OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, boo
     }
     if (eval_done && grad_done) break;
 
-    const T reg = (k_vio < o.kappa_reg) ? k_vio * o.gamma_reg : T(0);
-    reg_prev = reg;
-    if (!eval_factor<M>(z, th, pre, tr, reg, f)) status &= ~OD_ST_FACTOR_OK;
-    T D[M::NZ];
-    M::solve(f, r, D);                                   // affine (predictor) direction
-    if constexpr (CONES) {
-      const T aaff = step_length<M>(z, D, T(1), T(1), o.coop);
-      T kap = centering_kappa<M>(z, D, aaff);
-      kap = od_max(kap, o.kappa_eval * o.undercut_inv);
-#pragma unroll
-      for (int i = 0; i < M::NKROWS; ++i) r[M::KROWS[i]] -= kap;    // r(z; kappa) from r(z; 0)
-      if constexpr (M::NORT > 0) {
-#pragma unroll
-        for (int i = 0; i < M::NORT; ++i) r[M::ORTR[i]] += D[M::ORT1[i]] * D[M::ORT2[i]];
-      }
-      if constexpr (M::NSOC > 0) correction_cone<M, 0>(r, D);
-      M::solve(f, r, D);                                 // corrector direction, factors reused
-    }
-    const T vio = od_max(r_vio, k_vio);
-    const T tau = T(1) - od_min(o.eps_min, vio * vio);
-    T alpha = step_length<M>(z, D, tau, od_min(tau, T(0.99)), o.coop);
-    T zc[M::NZ];
-    T r_c = T(0), k_c = T(0);
-    for (int ls = 0; ls < o.max_ls; ++ls) {
-#pragma unroll
-      for (int i = 0; i < M::NZ; ++i) zc[i] = z[i] - alpha * D[i];
-      M::eval_r(zc, th, pre, tr, r);
-      r_c = viol_eq<M>(r);
-      k_c = viol_bil<M>(r);
-      if (r_c <= r_vio || k_c <= k_vio) break;
-      alpha *= T(0.5);
-    }
-#pragma unroll
-    for (int i = 0; i < M::NZ; ++i) z[i] = zc[i];
-    r_vio = r_c;
-    k_vio = k_c;
-    OD_TRACE_IT("dev it %d alpha %.17g r_vio %.6e k_vio %.6e\n", it + 1, (double)alpha, (double)r_vio, (double)k_vio);
+    ip_iteration<M>(o, th, pre, tr, z, r, r_vio, k_vio, reg_prev, status, it, f);
   }
   if (want_state) {
 #pragma unroll
