@@ -228,6 +228,27 @@ OD_HD bool eval_factor(const T* z, const T* th, const T* pre, const T* tr, T reg
   return M::factor(a, f);
 }
 
+// backtracking on z - alpha D until either violation does not increase (at most max_ls halvings); leaves z at the
+// accepted point, r = r(z; 0) and its violations
+template <class M, class T>
+OD_HD void line_search(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z, const T* D, T& alpha, T* r, T& r_vio, T& k_vio) {
+  T zc[M::NZ];
+  T r_c = T(0), k_c = T(0);
+  for (int ls = 0; ls < o.max_ls; ++ls) {
+#pragma unroll
+    for (int i = 0; i < M::NZ; ++i) zc[i] = z[i] - alpha * D[i];
+    M::eval_r(zc, th, pre, tr, r);
+    r_c = viol_eq<M>(r);
+    k_c = viol_bil<M>(r);
+    if (r_c <= r_vio || k_c <= k_vio) break;
+    alpha *= T(0.5);
+  }
+#pragma unroll
+  for (int i = 0; i < M::NZ; ++i) z[i] = zc[i];
+  r_vio = r_c;
+  k_vio = k_c;
+}
+
 // One predictor-corrector iteration at z (r = r(z; 0), r_vio / k_vio its violations): factor, affine
 // direction, centering, corrector direction, step length, backtracking line search.  Shared by the
 // lockstep loop below and the decoupled rollout (od_units.h) so that both do identical arithmetic.
@@ -256,21 +277,7 @@ OD_HD void ip_iteration(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z
   const T vio = od_max(r_vio, k_vio);
   const T tau = T(1) - od_min(o.eps_min, vio * vio);
   T alpha = step_length<M>(z, D, tau, od_min(tau, T(0.99)), o.coop);
-  T zc[M::NZ];
-  T r_c = T(0), k_c = T(0);
-  for (int ls = 0; ls < o.max_ls; ++ls) {
-#pragma unroll
-    for (int i = 0; i < M::NZ; ++i) zc[i] = z[i] - alpha * D[i];
-    M::eval_r(zc, th, pre, tr, r);
-    r_c = viol_eq<M>(r);
-    k_c = viol_bil<M>(r);
-    if (r_c <= r_vio || k_c <= k_vio) break;
-    alpha *= T(0.5);
-  }
-#pragma unroll
-  for (int i = 0; i < M::NZ; ++i) z[i] = zc[i];
-  r_vio = r_c;
-  k_vio = k_c;
+  line_search<M>(o, th, pre, tr, z, D, alpha, r, r_vio, k_vio);
   OD_TRACE_IT("dev it %d alpha %.17g r_vio %.6e k_vio %.6e\n", it + 1, (double)alpha, (double)r_vio, (double)k_vio);
 }
 
