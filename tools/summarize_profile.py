@@ -33,7 +33,7 @@ for k in ("k_rollout_state", "k_grad_knots"):
     out.append("%s SQ counters per dispatch (SQ_*_CYCLES in quad-cycles): %s" % (k, json.dumps({c: int(v) for c, v in sorted(m[k].items())})))
 out.append("HBM bytes per od_rollout (2*FETCH_SIZE + WRITE_SIZE, both kernels; FETCH_SIZE counts half of wide coalesced reads on gfx950): %.1f MB" % (tot / 1e6))
 s = m["k_rollout_state"]
-out.append("k_rollout_state: %d wavefronts, %.2f M VALU instructions per wavefront, %.2f quad-cycles per VALU instruction, VALU active %.0f %% of wave cycles, waiting on memory %.0f %%, issue stalls %.1f %%"
+out.append("k_rollout_state: %d wavefronts, %.2f M VALU instructions per wavefront, %.2f quad-cycles per VALU instruction, VALU active %.0f %% of wave cycles, SQ_WAIT_ANY (dependent-issue gaps and memory waits) %.0f %%, issue stalls %.1f %%"
            % (s["SQ_WAVES"], s["SQ_INSTS_VALU"] / s["SQ_WAVES"] / 1e6, s["SQ_WAVE_CYCLES"] / s["SQ_INSTS_VALU"],
               100 * s["SQ_ACTIVE_INST_VALU"] / s["SQ_WAVE_CYCLES"], 100 * s["SQ_WAIT_ANY"] / s["SQ_WAVE_CYCLES"],
               100 * s["SQ_WAIT_INST_ANY"] / s["SQ_WAVE_CYCLES"]))
