@@ -145,6 +145,15 @@ int od_ls_fit(od_handle h, long B, int N, int ny, int nzb, const void* eta, cons
  * z: nz per problem; dz: nzq x ngc per problem (rows = solution block, cols = leading theta
  * columns, see od_raw_grad_dims); dz may be NULL (diff_sol = false). */
 int od_raw_grad_dims(int model, int* nzq, int* ngc);
+
+/* The whole solution of a step: z (nz per problem) at kappa_eval and dz = d z / d(q1, q2, u1)
+ * (nz x (2nq + nu) col-major per problem; NULL = no differentiation) at kappa_grad -- what RoboDojo's `process!`
+ * fills sim.traj.gamma / sim.traj.b and sim.grad.dgamma1d* / db1d* from (sized in src/dynamics.jl:36-46).
+ * od_model_indices gives the rows: which = OD_IDX_CONFIGURATION (next configuration q3), OD_IDX_GAMMA (impact
+ * impulses, nc of them), OD_IDX_B (friction impulses, nb); returns the count, writes at most cap indices. */
+enum od_index_set { OD_IDX_CONFIGURATION = 0, OD_IDX_GAMMA = 1, OD_IDX_B = 2 };
+int od_model_indices(int model, int which, int* idx, int cap);
+int od_step_full(od_handle h, long B, const void* x, const void* u, void* z, void* dz, int* status, int* iters);
 int od_ip_solve(od_handle h, long B, const void* z0, const void* theta, void* z, void* dz,
                 int* status, int* iters);
 

@@ -65,6 +65,8 @@ SIGNATURES = {
     "od_ip_solve": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _VP, _IP, _IP]),
     "od_rocket": (C.c_int, [_VP, C.c_long, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _IP]),
     "od_soc_project": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _IP]),
+    "od_model_indices": (C.c_int, [C.c_int, C.c_int, _IP, C.c_int]),
+    "od_step_full": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _VP, _IP, _IP]),
     "od_rocket_rollout": (C.c_int, [_VP, C.c_long, C.c_int, C.c_int, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _IP]),
     "od_f_host": (C.c_int, [_VP, _VP, _VP, _VP]),
     "od_fx_host": (C.c_int, [_VP, _VP, _VP, _VP]),
@@ -95,6 +97,17 @@ class Library:
         v = [C.c_int() for _ in range(5)]
         self.check(self.cdll.od_model_dims(MODEL_IDS[model], *[C.byref(x) for x in v]))
         return dict(zip(["nq", "nu", "nz", "ntheta", "nfric"], [x.value for x in v]))
+
+    def model_indices(self, model):
+        """z indices (0-based) of the next configuration, the impact impulses gamma and the friction impulses b"""
+        out = {}
+        for key, which in (("q", 0), ("gamma", 1), ("b", 2)):
+            buf = (C.c_int * 16)()
+            n = self.cdll.od_model_indices(MODEL_IDS[model], which, buf, 16)
+            if n < 0:
+                self.check(n)
+            out[key] = [buf[i] for i in range(n)]
+        return out
 
     def raw_grad_dims(self, model):
         a, b = C.c_int(), C.c_int()

@@ -422,6 +422,8 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
     o.write(arr("ORT1", m.ort[0]) + arr("ORT2", m.ort[1]) + arr("ORTR", m.ortr))
     o.write(arr("SOCOFF", soc_off) + arr("SOC1", soc_flat_p) + arr("SOC2", soc_flat_d) + arr("SOCR", socr_flat))
     o.write(arr("EQUR", m.equr) + arr("BIL", m.bil) + arr("ZQ", m.idx_zq))
+    o.write("  static constexpr int NGAM = %d, NBFR = %d;\n" % (len(m.idx_gamma), len(m.idx_b)))
+    o.write(arr("GAM", m.idx_gamma) + arr("BFR", m.idx_b))
     o.write(arr("KROWS", d.kappa_rows))
     o.write("  static constexpr int NKROWS = %d;\n" % len(d.kappa_rows))
     # posthoc clamp entries: (nnz slot, partner variable)

@@ -51,6 +51,10 @@ class ModelSpec:
     fric_default: List[float] = field(default_factory=list)
     # which z entries are the next configuration, which theta slots feed the gradient
     idx_zq: List[int] = field(default_factory=list)
+    # which z entries are the impact impulses gamma and the friction impulses b (RoboDojo `process!` /
+    # sim.traj.gamma, sim.traj.b; sized by nc / nb in src/dynamics.jl:36-46)
+    idx_gamma: List[int] = field(default_factory=list)
+    idx_b: List[int] = field(default_factory=list)
     # device elimination order: list of (row, col) static pivots
     elim: List[Tuple[int, int]] = field(default_factory=list)
     # static pivots whose value is a strictly positive cone variable that may underflow towards 0
@@ -157,7 +161,7 @@ def acrobot_impact() -> ModelSpec:
         # simulator_impact.jl:16-31
         ort=([2, 3], [4, 5]), soc=[], equr=[0, 1, 2, 3], ortr=[4, 5], socri=[], bil=[4, 5],
         z_init=[("q", 0), ("q", 1), 1.0, 1.0, 1.0, 1.0],                   # :34-38
-        kind="mech", nfric=0, idx_zq=[0, 1],
+        kind="mech", nfric=0, idx_zq=[0, 1], idx_gamma=[2, 3],
         elim=[(2, 4), (3, 5), (4, 2), (5, 3)], floor_pivots=[(4, 2), (5, 3)],
         opts=dict(IP_DEFAULT, kappa_tol=1e-4, kappa_grad_tol=1e-3),       # examples/acrobot.jl:15-23
     )
@@ -228,7 +232,7 @@ def cartpole_friction() -> ModelSpec:
         ort=([], []), soc=[([2, 4], [6, 8]), ([3, 5], [7, 9])],
         equr=list(range(6)), ortr=[], socri=[[6, 7], [8, 9]], bil=[6, 7, 8, 9],
         z_init=[("q", 0), ("q", 1), 1.0, 1.0, 0.1, 0.1, 1.0, 1.0, 0.1, 0.1],   # :36-42
-        kind="mech", nfric=2, fric_default=[0.1, 0.1], idx_zq=[0, 1],
+        kind="mech", nfric=2, fric_default=[0.1, 0.1], idx_zq=[0, 1], idx_b=[4, 5],
         # rows: 2: sb0-vT1 (pivot sb0=z8), 3: psi0-.. (pivot psi0=z2), 4: sb1 (z9), 5: psi1 (z3)
         # cone rows (6,7) / (8,9): one local pivot (tail row -> b, coefficient s_psi) after a runtime
         # role swap (head<->tail, b<->s_psi) when psi > s_psi; the other row/unknown goes to the tail
@@ -354,7 +358,8 @@ def planar_push() -> ModelSpec:
     return ModelSpec(
         name="planar_push", model_id=4, nq=nq, nu=nu, nz=nz, nth=nth, z=z, th=th, kappa=k, r=r,
         ort=([5], [6]), soc=soc, equr=list(range(20)), ortr=[20], socri=socri, bil=list(range(20, 35)),
-        z_init=z_init, kind="mech", nfric=0, idx_zq=list(range(5)), elim=elim, swaps=swaps,
+        z_init=z_init, kind="mech", nfric=0, idx_zq=list(range(5)), idx_gamma=[5], idx_b=list(range(12, 21)),
+        elim=elim, swaps=swaps,
         floor_pivots=[(20, 5)],
         opts=dict(IP_DEFAULT, kappa_tol=1e-4, kappa_grad_tol=1e-2),       # examples/planar_push.jl:21-22
     )
@@ -524,7 +529,8 @@ def hopper() -> ModelSpec:
         equr=list(range(12)), ortr=[12, 13, 14, 15], socri=[[16, 17], [18, 19]], bil=list(range(12, 20)),
         z_init=z_init, kind="mech", nfric=2,
         fric_default=[P["friction_body_world"], P["friction_foot_world"]],
-        idx_zq=[0, 1, 2, 3], elim=elim, floor_pivots=[(12 + i, 4 + i) for i in range(4)],
+        idx_zq=[0, 1, 2, 3], idx_gamma=[4, 5, 6, 7], idx_b=[14, 15],
+        elim=elim, floor_pivots=[(12 + i, 4 + i) for i in range(4)],
         swaps=[((16, 17), (14, 16)), ((18, 19), (15, 17))],
         opts=dict(IP_DEFAULT, kappa_tol=1e-4, kappa_grad_tol=1e-3),       # examples/hopper.jl:42
         notes="RoboDojo hopper, restated from recall; constants unverified",

@@ -729,6 +729,38 @@ int od_ls_fit(od_handle h, long B, int N, int ny, int nzb, const void* eta, cons
   return run_ls(h, B, N, ny, nzb, (const double*)eta, fv, h->work, M, status);
 }
 
+int od_model_indices(int model, int which, int* idx, int cap) {
+  const ModelVT* vt = vt_of(model);
+  if (!vt) return fail(OD_ERR_INVALID, "od_model_indices: unknown model");
+  int n = 0;
+  const int* src = nullptr;
+  int zq[16];
+  if (which == OD_IDX_CONFIGURATION) {
+    // the solution block: the next configuration q3 (mechanical models) / next state (rocket) / projected control
+    n = vt->nzq;
+    for (int i = 0; i < n && i < 16; ++i) zq[i] = i;      // every model stores it first (csrc/gen/*.h: ZQ = 0..nzq-1)
+    src = zq;
+  } else if (which == OD_IDX_GAMMA) { n = vt->ngam; src = vt->gam; }
+  else if (which == OD_IDX_B) { n = vt->nbfr; src = vt->bfr; }
+  else return fail(OD_ERR_INVALID, "od_model_indices: unknown index set");
+  if (idx) for (int i = 0; i < n && i < cap; ++i) idx[i] = src[i];
+  return n;
+}
+
+int od_step_full(od_handle h, long B, const void* x, const void* u, void* z, void* dz, int* status, int* iters) {
+  if (int rc = check_mech(h, "od_step_full")) return rc;
+  if (B <= 0) return OD_OK;
+  if (!x || !z || (h->vt->nu > 0 && !u)) return fail(OD_ERR_INVALID, "od_step_full: null x/u/z");
+  if (dz && !fusable(h)) return fail(OD_ERR_UNSUPPORTED, "od_step_full: finite undercut with kappa_eval != kappa_grad");
+  const ModelVT* vt = h->vt;
+  FullArgs<double> a;
+  a.s = step_args(h, B, B, x, u, nullptr, nullptr, nullptr, nullptr, status, iters, dz ? 1 : 0);
+  a.z = mkview<double>(z, vt->nz, B, h->layout);
+  a.dz = mkview<double>(dz, vt->nz * (2 * vt->nq + vt->nu), B, h->layout);
+  OD_HIP(vt->step_full(a, ppw_of(h, B), h->stream));
+  return OD_OK;
+}
+
 int od_ip_solve(od_handle h, long B, const void* z0, const void* theta, void* z, void* dz, int* status, int* iters) {
   if (!h) return fail(OD_ERR_INVALID, "od_ip_solve: null handle");
   if (B <= 0) return OD_OK;

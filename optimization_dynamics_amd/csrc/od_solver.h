@@ -12,6 +12,7 @@
 // All model structure (index sets, sparse KKT elimination) is compile-time (csrc/gen/*.h), every
 // loop below is fully unrolled and every array lives in registers.
 #pragma once
+#include <type_traits>
 #include "od_math.h"
 
 #ifdef OD_TRACE   // test-harness builds only (tests/host_emu): per-iteration trace to stdout
@@ -281,6 +282,10 @@ OD_HD void ip_iteration(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z
   OD_TRACE_IT("dev it %d alpha %.17g r_vio %.6e k_vio %.6e\n", it + 1, (double)alpha, (double)r_vio, (double)k_vio);
 }
 
+// sinks that want every row of dz (not only the solution block ZQ) declare `static constexpr bool ALL_ROWS = true`
+template <class S, class = void> struct sink_all_rows : std::false_type {};
+template <class S> struct sink_all_rows<S, std::void_t<decltype(S::ALL_ROWS)>> : std::bool_constant<S::ALL_ROWS> {};
+
 // Sink concept:  void grad(int i /*row in ZQ*/, int c /*grad column*/, T v)
 //
 // z: in = initial guess, out = iterate at (r_tol, kappa_eval) convergence (or the last iterate).
@@ -319,8 +324,13 @@ OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, boo
 #pragma unroll
         for (int k = 0; k < M::NNZTH; ++k) b[M::RTH_ROW[k]] = (M::RTH_COL[k] == c) ? g[k] : b[M::RTH_ROW[k]];
         M::solve(f, b, b);
+        if constexpr (sink_all_rows<Sink>::value) {
 #pragma unroll
-        for (int i = 0; i < M::NZQ; ++i) sink.grad(i, c, -b[M::ZQ[i]]);
+          for (int i = 0; i < M::NZ; ++i) sink.grad(i, c, -b[i]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < M::NZQ; ++i) sink.grad(i, c, -b[M::ZQ[i]]);
+        }
       }
       }
       grad_done = true;

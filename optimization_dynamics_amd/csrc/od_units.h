@@ -295,6 +295,41 @@ template <class M, class T> OD_HD void unit_bundle_sample(const BundleArgs<T>& b
   if (ba.status.ok()) ba.status.at(0, p) = st;
 }
 
+// ---- whole solution of a step: z at kappa_eval and dz/d(q1, q2, u1) at kappa_grad, every row --------------
+// What RoboDojo's `process!` reads contact forces and their sensitivities from (sim.traj.gamma / b, sim.grad.dgamma1d*,
+// db1d*: sized in src/dynamics.jl:36-46).  One fused launch (not the two-pass split): a feature
+// path, not the hot one.
+template <class T> struct FullArgs {
+  StepArgs<T> s;      // x, u, opts, h, fric
+  View<T> z;          // NZ
+  View<T> dz;         // NZ x NGC col-major
+};
+template <class M, class T> struct FullSink {
+  static constexpr bool DEFER_GRAD = false;
+  static constexpr bool FULL_STATE = true;
+  static constexpr bool ALL_ROWS = true;
+  const FullArgs<T>& a;
+  long b;
+  OD_HD void defer(const T*, T) {}
+  OD_HD void grad(int i, int c, T v) { if (a.dz.ok()) a.dz.at(i + M::NZ * c, b) = v; }
+};
+template <class M, class T> OD_HD void unit_step_full(const FullArgs<T>& a, long b) {
+  constexpr int nq = M::NQ, n = 2 * M::NQ;
+  T x[n], u[M::NU > 0 ? M::NU : 1], th[M::NTH], z[M::NZ];
+#pragma unroll
+  for (int i = 0; i < n; ++i) x[i] = a.s.x.at(i, b);
+#pragma unroll
+  for (int i = 0; i < M::NU; ++i) u[i] = a.s.u.at(i, b);
+  mech_setup<M>(x, x + nq, u, a.s.fric, a.s.h, th, z);
+  FullSink<M, T> sink{a, b};
+  int it[2];
+  const int st = ip_step_grad<M>(a.s.opts, th, z, true, a.s.want_grad != 0, sink, it);
+#pragma unroll
+  for (int i = 0; i < M::NZ; ++i) a.z.at(i, b) = z[i];
+  if (a.s.status.ok()) a.s.status.at(0, b) = st;
+  if (a.s.iters.ok()) { a.s.iters.at(0, b) = it[0]; a.s.iters.at(1, b) = it[1]; }
+}
+
 // ---- raw interior-point solve on user-supplied (z0, theta): rocket dynamics / projection ------
 // (src/models/rocket/dynamics.jl:101-210).  dz: NZQ x NGC col-major (rows ZQ, first NGC theta cols)
 template <class T> struct RawArgs {

@@ -133,6 +133,32 @@ class ImplicitDynamics:
         self.lib.check(self.lib.cdll.od_step_grad_compact(self._h, B, _ptr(X), _ptr(U), _ptr(Q3), _ptr(G), _ptr(st), _ptr(it)))
         return Q3, G.view(nzb, nq, B).transpose(0, 1), st, it
 
+    def step_full(self, X, U, grads=True):
+        """the whole solution: Z (nz, B) at kappa_eval, DZ (nz, 2nq+nu, B) = dz/d(q1, q2, u1) at kappa_grad, status, iters;
+        rows via `self.indices` = {"q": [...], "gamma": [...], "b": [...]} (RoboDojo's sim.traj.gamma / b, sim.grad.*)"""
+        self._sync_friction(); self._use_current_stream()
+        X, U = self._prep(X), self._prep(U)
+        B = X.shape[-1]
+        nz = self.lib.model_dims(self.model.name)["nz"]
+        ngc = 2 * self.model.nq + self.model.nu
+        Z = self._new(nz, B)
+        DZf = self._new(nz * ngc, B) if grads else None
+        st = self._new(B, dtype=torch.int32); it = self._new(2, B, dtype=torch.int32)
+        self.lib.check(self.lib.cdll.od_step_full(self._h, B, _ptr(X), _ptr(U), _ptr(Z), _ptr(DZf), _ptr(st), _ptr(it)))
+        DZ = DZf.view(ngc, nz, B).transpose(0, 1) if grads else None
+        return Z, DZ, st, it
+
+    @property
+    def indices(self):
+        return self.lib.model_indices(self.model.name)
+
+    def contact_forces(self, X, U, grads=True):
+        """gamma (nc, B), b (nb, B) and, with grads, d gamma / d(q1, q2, u1) (nc, 2nq+nu, B), d b / d(...) (nb, ..., B)"""
+        Z, DZ, st, it = self.step_full(X, U, grads)
+        ix = self.indices
+        g, b = ix["gamma"], ix["b"]
+        return Z[g], Z[b], (DZ[g] if grads else None), (DZ[b] if grads else None), st
+
     def rollout(self, x1, U, grads=True, out=None):
         """iLQR.rollout + derivative sweep.  x1: (2nq, B); U: (nu, T, B)
         -> X (2nq, T+1, B), A (2nq, 2nq, T, B), Bm (2nq, nu, T, B), status (T, B), iters (2, T, B).

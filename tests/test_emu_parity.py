@@ -61,6 +61,11 @@ def test_rocket_f32(oracle, emu_lib):
     P.check_rocket(oracle, emu_lib, "cpu", 16, dtype=torch.float32)
 
 
+@pytest.mark.parametrize("name", ["acrobot_impact", "cartpole_friction", "hopper", "planar_push", "acrobot_nominal"])
+def test_step_full_contact_forces(oracle, emu_lib, name):
+    P.check_step_full(oracle, emu_lib, "cpu", name, 48)
+
+
 def test_soc_projection(oracle, emu_lib):
     P.check_soc_projection(oracle, emu_lib, "cpu", 48)
 
