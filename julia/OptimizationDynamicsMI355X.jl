@@ -4,7 +4,7 @@
 module OptimizationDynamicsMI355X
 
 export ImplicitDynamicsMI355X, f, fx, fu, state_to_configuration, od_step_grad!, od_rollout!,
-       RocketInfoMI355X, od_rocket!, od_soc_project!
+       RocketInfoMI355X, od_rocket!, od_soc_project!, od_step_full!, model_indices
 
 const LIB = get(ENV, "OD_MI355X_LIB", joinpath(@__DIR__, "..", "optimization_dynamics_amd", "libod_mi355x.so"))
 
@@ -93,6 +93,19 @@ function od_rollout!(m::ImplicitDynamicsMI355X, B, T, x1, U, X, A, Bm)
     check(ccall((:od_set_layout, LIB), Cint, (Ptr{Cvoid}, Cint), m.h, 1))
     check(ccall((:od_rollout, LIB), Cint, (Ptr{Cvoid}, Clong, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}),
                 m.h, B, T, pointer(x1), pointer(U), pointer(X), pointer(A), pointer(Bm), C_NULL, C_NULL))
+end
+
+"whole solution on device arrays (contact impulses and their sensitivities): Z nz×B, DZ (nz*(2nq+nu))×B; rows via model_indices"
+function od_step_full!(m::ImplicitDynamicsMI355X, B, X, U, Z, DZ)
+    check(ccall((:od_set_layout, LIB), Cint, (Ptr{Cvoid}, Cint), m.h, 1))
+    check(ccall((:od_step_full, LIB), Cint, (Ptr{Cvoid}, Clong, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}),
+                m.h, B, pointer(X), pointer(U), pointer(Z), pointer(DZ), C_NULL, C_NULL))
+end
+"1-based z indices of (:q | :γ | :b) for a model"
+function model_indices(model::Symbol, which::Symbol)
+    buf = zeros(Cint, 16)
+    n = ccall((:od_model_indices, LIB), Cint, (Cint, Cint, Ptr{Cint}, Cint), MODEL_IDS[model], Dict(:q => 0, :γ => 1, :b => 2)[which], buf, 16)
+    return Int.(buf[1:n]) .+ 1
 end
 
 # rocket (src/models/rocket/dynamics.jl): one OD_ROCKET_DYNAMICS handle plays ip_dyn and ip_proj
