@@ -278,8 +278,11 @@ OD_HD void ip_iteration(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z
   const T vio = od_max(r_vio, k_vio);
   const T tau = T(1) - od_min(o.eps_min, vio * vio);
   T alpha = step_length<M>(z, D, tau, od_min(tau, T(0.99)), o.coop);
+#ifdef OD_TRACE
+  const T alpha0_ = alpha;
+#endif
   line_search<M>(o, th, pre, tr, z, D, alpha, r, r_vio, k_vio);
-  OD_TRACE_IT("dev it %d alpha %.17g r_vio %.6e k_vio %.6e\n", it + 1, (double)alpha, (double)r_vio, (double)k_vio);
+  OD_TRACE_IT("dev it %d alpha %.17g r_vio %.6e k_vio %.6e alpha0 %.6e\n", it + 1, (double)alpha, (double)r_vio, (double)k_vio, (double)alpha0_);
 }
 
 // sinks that want every row of dz (not only the solution block ZQ) declare `static constexpr bool ALL_ROWS = true`
