@@ -54,3 +54,26 @@ def test_parity_sweep(oracle, gpu_lib):
             # implicit gradients: 1e-4 except at the reference algorithm's own noise floor (ratios of ~1e-23 cone
             # variables): median at rounding level, 99th percentile inside the tolerance
             assert r["grad_rel_median"] < 1e-9 and r["grad_rel_p99"] < P.GRAD_TOL and r["frac_grad_within_1e4"] >= 0.995, (name, r)
+
+
+def test_rollout_parity_sweep(oracle, gpu_lib):
+    """headline-shaped rollouts (hopper, T = 100) against the oracle's rollouts: the recursion amplifies rounding
+    differences through contact-mode switches, so the comparison is knot by knot in time"""
+    B, T = 512, 100
+    x1, U = W.hopper_rollout_inputs(B, T, seed=5, u_sigma=1.0)
+    im = P.make_im("hopper", gpu_lib, DEV)
+    X, A, Bm, st, it, _ = im.rollout(torch.tensor(x1), torch.tensor(U))
+    Xn, stn = X.cpu().numpy(), st.cpu().numpy()
+    Xo, Ao, Bo, bad = oracle.rollout(P.make_sim(oracle, "hopper"), x1, U)
+    ok = ((stn & 3) == 3).all(0)
+    err = np.abs(Xn - Xo)[:, :, ok].max(0) / np.maximum(1e-2, np.abs(Xo)[:, :, ok].max(0))      # (T+1, n_ok)
+    rows = {"trajectories": B, "all_knots_converged": int(ok.sum())}
+    for t in (1, 10, 25, 50, 100):
+        rows["t=%d" % t] = dict(median=float(np.median(err[t])), p99=float(np.percentile(err[t], 99)), max=float(err[t].max()),
+                                frac_within_1e6=float((err[t] < P.STATE_TOL).mean()))
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    json.dump(rows, open(os.path.join(d, "rollout_parity_sweep.json"), "w"), indent=1)
+    assert ok.mean() > 0.9
+    assert err[:11].max() < P.STATE_TOL
+    assert np.median(err[-1]) < 1e-6 and (err[-1] < P.STATE_TOL).mean() > 0.9
