@@ -268,7 +268,7 @@ template <class T> View<const T> mkcview(const void* p, long E, long K, int layo
 int ppw_of(const od_handle_s* h, long n) { return h->ppw > 0 ? h->ppw : od_auto_ppw(n); }
 
 // pass-1 launch shape: 4 wavefronts per workgroup (one per SIMD) while that still spreads the batch over
-// the chip, problems per wavefront from od_auto_ppw (aims at ~256 resident wavefronts)
+// the chip, problems per wavefront from od_auto_ppw (aims at one resident wavefront per SIMD)
 LaunchCfg cfg_of(const od_handle_s* h, long n) {
   LaunchCfg c;
   c.ppw = ppw_of(h, n);
