@@ -654,8 +654,7 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
         o.write("    T t_[MTAIL];\n")
         for ii, i in enumerate(el.tail_rows):
             o.write("    t_[%d] = y_%d;\n" % (ii, i))
-        o.write("    T tl_[MTAIL * MTAIL];\n#pragma unroll\n    for (int i = 0; i < MTAIL * MTAIL; ++i) tl_[i] = f.v[TAIL_BASE + i];\n")
-        o.write("    od_lu_solve<T, MTAIL>(tl_, f.piv, t_);\n")
+        o.write("    od_lu_solve<T, MTAIL>(od_tail_view<T, TAIL_BASE>(f), f.piv, t_);\n")
         for jj, j in enumerate(el.tail_cols):
             o.write("    const T x_%d = t_[%d];\n" % (j, jj))
     for (prw, pc, ipval, us) in reversed(el.bwd):

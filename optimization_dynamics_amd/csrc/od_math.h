@@ -198,7 +198,14 @@ template <class T, int N> OD_HD bool od_lu_factor(T* A, int* piv) {
   return ok;
 }
 
-template <class T, int N> OD_HD void od_lu_solve(const T* A, const int* piv, T* b) {
+// read-only view of the tail block inside a factor store (registers or any other storage with v[i])
+template <class T, int BASE, class F> struct TailView {
+  const F& f;
+  OD_HD T operator[](int i) const { return f.v[BASE + i]; }
+};
+template <class T, int BASE, class F> OD_HD TailView<T, BASE, F> od_tail_view(const F& f) { return TailView<T, BASE, F>{f}; }
+
+template <class T, int N, class Mat> OD_HD void od_lu_solve(const Mat& A, const int* piv, T* b) {
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const int p = piv[k];

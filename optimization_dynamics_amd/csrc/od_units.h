@@ -37,6 +37,43 @@ template <class T> struct View {
   OD_HD Cursor cursor(long b) const { Cursor c{p + b * sb, se}; OD_OPAQUE_PTR(c.q); return c; }
 };
 
+// ---- where the KKT factors of one problem live -------------------------------------------------------------
+// RegFact: the generated Fact struct (registers; what does not fit spills to scratch).  LdsFact: LDS, 16 lane slots
+// per 64-thread workgroup, for models whose factors do not fit the register file anyway (planar push: 325
+// doubles per lane = the whole of its 2.5 KB scratch frame).  LDS is ~10x closer than scratch, but 41.6 KB per
+// wavefront allow only 3 wavefronts per CU, so the launcher uses it when the batch fits one such round
+// (od_model_tu.inc).  Accesses go through an opaque offset so that the compiler cannot keep the values in
+// registers (and spill those) after all.
+template <class M, class T> struct RegFactStore {
+  using Fact = typename M::template Fact<T>;
+  OD_HD static Fact make() { return Fact{}; }
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class M, class T> struct LdsFactStore {
+  static constexpr int SLOTS = 16;
+  struct Fact {
+    struct Arr {
+      T* base;
+      __device__ __forceinline__ T& operator[](int i) const {
+        unsigned o = (unsigned)i * SLOTS;
+        asm volatile("" : "+v"(o));
+        return base[o];
+      }
+    } v;
+    int piv[M::MTAIL > 0 ? M::MTAIL : 1];
+    bool sw[M::NSWAP > 0 ? M::NSWAP : 1];
+  };
+  __device__ __forceinline__ static Fact make() {
+    __shared__ T lds_fact[(M::NFACT > 0 ? M::NFACT : 1) * SLOTS];
+    Fact f;
+    f.v.base = lds_fact + (threadIdx.x & (SLOTS - 1));
+    return f;
+  }
+};
+#else   // the host test build has no LDS: same interface, registers
+template <class M, class T> struct LdsFactStore : RegFactStore<M, T> {};
+#endif
+
 // ---- f / fx / fu (src/dynamics.jl:81-128) ------------------------------------------------------
 // Two passes.  Pass 1 ("state"): the interior-point solve of every knot (sequential in t for
 // rollouts), which records per knot the iterate z_g at which the reference's grad simulator would
@@ -93,14 +130,15 @@ template <class M, class T> struct DeferSink {
 };
 
 // pass 1 for one knot k given its state and control in registers; returns q3 in q3out
-template <class M, class T>
+template <class M, class T, class Store = RegFactStore<M, T>>
 OD_HD void knot_state(const StepArgs<T>& a, long k, const T* xin, const T* uin, T* q3out) {
   constexpr int nq = M::NQ;
   T th[M::NTH], z[M::NZ];
   mech_setup<M>(xin, xin + nq, uin, a.fric, a.h, th, z);
   DeferSink<M, T> sink{a.zg, k};
   int it[2];
-  const int st = ip_step_grad<M>(a.opts, th, z, true, a.want_grad != 0, sink, it);
+  auto f = Store::make();
+  const int st = ip_step_grad<M, T, DeferSink<M, T>>(a.opts, th, z, true, a.want_grad != 0, sink, it, f);
 #pragma unroll
   for (int i = 0; i < nq; ++i) q3out[i] = z[M::ZQ[i]];
   if (a.d.ok()) {
@@ -118,14 +156,14 @@ OD_HD void knot_state(const StepArgs<T>& a, long k, const T* xin, const T* uin, 
 }
 
 // independent knots (od_step, od_step_grad pass 1)
-template <class M, class T> OD_HD void unit_step_state(const StepArgs<T>& a, long b) {
+template <class M, class T, class Store = RegFactStore<M, T>> OD_HD void unit_step_state(const StepArgs<T>& a, long b) {
   constexpr int nq = M::NQ, n = 2 * M::NQ;
   T x[n], u[M::NU > 0 ? M::NU : 1], q3[nq];
 #pragma unroll
   for (int i = 0; i < n; ++i) x[i] = a.x.at(i, b);
 #pragma unroll
   for (int i = 0; i < M::NU; ++i) u[i] = a.u.at(i, b);
-  knot_state<M, T>(a, b, x, u, q3);
+  knot_state<M, T, Store>(a, b, x, u, q3);
 }
 
 // rollouts (od_rollout pass 1): T sequential knots per trajectory, state carried in registers.
@@ -136,7 +174,7 @@ template <class T> struct RolloutArgs {
   int Tn;
 };
 
-template <class M, class T> OD_HD void unit_rollout_state(const RolloutArgs<T>& ra, long b) {
+template <class M, class T, class Store = RegFactStore<M, T>> OD_HD void unit_rollout_state(const RolloutArgs<T>& ra, long b) {
   constexpr int nq = M::NQ, n = 2 * M::NQ;
   const StepArgs<T>& a = ra.s;
   T x[n], u[M::NU > 0 ? M::NU : 1], q3[nq];
@@ -163,7 +201,7 @@ template <class M, class T> OD_HD void unit_rollout_state(const RolloutArgs<T>& 
 #pragma unroll
       for (int i = 0; i < M::NU; ++i) un[i] = c.get();
     }
-    knot_state<M, T>(a, k, x, u, q3);
+    knot_state<M, T, Store>(a, k, x, u, q3);
 #pragma unroll
     for (int i = 0; i < nq; ++i) { x[i] = x[nq + i]; x[nq + i] = q3[i]; }
   }
@@ -275,7 +313,7 @@ template <class T> struct BundleArgs {
   View<int> status;       // per problem p
 };
 
-template <class M, class T> OD_HD void unit_bundle_sample(const BundleArgs<T>& ba, long p) {
+template <class M, class T, class Store = RegFactStore<M, T>> OD_HD void unit_bundle_sample(const BundleArgs<T>& ba, long p) {
   constexpr int nq = M::NQ, n = 2 * M::NQ, nzb = 2 * M::NQ + M::NU;
   const StepArgs<T>& a = ba.s;
   const long b = p / (ba.N + 1);
@@ -289,7 +327,8 @@ template <class M, class T> OD_HD void unit_bundle_sample(const BundleArgs<T>& b
   mech_setup<M>(x, x + nq, u, a.fric, a.h, th, z);
   NoGradSink<T> sink;
   int it[2];
-  const int st = ip_step_grad<M>(a.opts, th, z, true, false, sink, it);
+  auto f = Store::make();
+  const int st = ip_step_grad<M, T, NoGradSink<T>>(a.opts, th, z, true, false, sink, it, f);
 #pragma unroll
   for (int k = 0; k < nq; ++k) ba.feta.at(k, p) = z[M::ZQ[k]];
   if (ba.status.ok()) ba.status.at(0, p) = st;
