@@ -124,6 +124,10 @@ __device__ __forceinline__ bool od_any_lane(bool pred) { return __builtin_amdgcn
 inline bool od_any_lane(bool pred) { return pred; }
 #endif
 
+// x * 2^e, exact
+OD_HD double od_ldexp(double x, int e) { return __builtin_ldexp(x, e); }
+OD_HD float od_ldexp(float x, int e) { return __builtin_ldexpf(x, e); }
+
 template <class T> OD_HD T od_min(T a, T b) { return a < b ? a : b; }
 template <class T> OD_HD T od_max(T a, T b) { return a > b ? a : b; }
 // IEEE maxNum (one instruction on the device; a NaN operand is dropped)

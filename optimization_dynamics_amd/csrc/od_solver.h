@@ -112,17 +112,20 @@ template <class T> __device__ __forceinline__ T coop_min4(T v, int ppw) {
 }
 __device__ __forceinline__ int coop_group(int ppw) { return (((int)threadIdx.x & 63) / ppw) & 3; }
 template <int R> __device__ __forceinline__ int od_row_ror(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x120 + R, 0xF, 0xF, false); }
-// bitwise OR over the four copies
-__device__ __forceinline__ int coop_or4(int v, int ppw) {
-  if (ppw == 4) { v |= od_row_ror<4>(v); v |= od_row_ror<8>(v); }
-  else if (ppw == 2) { v |= od_row_ror<2>(v); v |= od_row_ror<4>(v); }
-  else { v |= od_row_ror<1>(v); v |= od_row_ror<2>(v); }
+// bitwise OR over ALL 16/ppw copies of a problem, and the index of a lane among them
+__device__ __forceinline__ int coop_or_all(int v, int ppw) {
+  if (ppw <= 1) v |= od_row_ror<1>(v);
+  if (ppw <= 2) v |= od_row_ror<2>(v);
+  v |= od_row_ror<4>(v);
+  v |= od_row_ror<8>(v);
   return v;
 }
+__device__ __forceinline__ int coop_copy(int ppw) { return ((int)threadIdx.x & 15) / ppw; }
 #else   // the host test build runs lanes one after the other: no cooperation
 template <class T> OD_HD T coop_min4(T v, int) { return v; }
 OD_HD int coop_group(int) { return 0; }
-OD_HD int coop_or4(int v, int) { return v; }
+OD_HD int coop_or_all(int v, int) { return v; }
+OD_HD int coop_copy(int) { return 0; }
 #endif
 
 template <class M> constexpr bool soc_uniform() {
@@ -241,8 +244,8 @@ OD_HD bool eval_factor(const T* z, const T* th, const T* pre, const T* tr, T reg
 // backtracking on z - alpha D until either violation does not increase (at most max_ls trials, the last one is kept
 // regardless); leaves z at the accepted point, r = r(z; 0) and its violations.
 // Small models with lane copies (Opts::coop): a solve that jams spends most of its time here (acrobot at its joint
-// limit: ~15 trials in each of its 100 iterations), so after two sequential trials the four copies try four step
-// sizes at once, agree on the first accepted one (the same one the sequential loop would find) and re-evaluate it.
+// limit: ~15 trials in each of its 100 iterations), so after two sequential trials the 16/ppw copies each try a step
+// size, agree on the first accepted one (the same one the sequential loop would find) and re-evaluate it.
 template <class M> constexpr bool parallel_line_search() { return M::NZ <= 10; }
 
 template <class M, class T>
@@ -269,26 +272,20 @@ OD_HD void line_search(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z,
   }
   if constexpr (parallel_line_search<M>()) {
     if (par && !done && ls < o.max_ls) {
-      // alpha is the step of trial `ls`; copy g tries trial j0 + g
-      const int g = coop_group(o.coop);
+      // alpha is the step of trial `ls`; the G = 16/ppw copies try trials j0 .. j0 + G - 1
+      const int G = 16 / o.coop, g = coop_copy(o.coop);
       bool found = false;
-      for (int j0 = ls; j0 < o.max_ls && !found; j0 += 4) {
-        T aj = alpha;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) aj = (i < g) ? aj * T(0.5) : aj;
+      for (int j0 = ls; j0 < o.max_ls && !found; j0 += G) {
+        const T aj = od_ldexp(alpha, -g);
         const bool acc = ls_trial<M>(th, pre, tr, z, D, aj, r_vio, k_vio, zc, r, r_c, k_c) && (j0 + g < o.max_ls);
-        const int m = coop_or4(acc ? (1 << g) : 0, o.coop);
+        const int m = coop_or_all(acc ? (1 << g) : 0, o.coop);
         if (m != 0) {
-          const int gs = (m & 1) ? 0 : (m & 2) ? 1 : (m & 4) ? 2 : 3;      // first accepted trial of the round
-#pragma unroll
-          for (int i = 0; i < 3; ++i) alpha = (i < gs) ? alpha * T(0.5) : alpha;
+          alpha = od_ldexp(alpha, -__builtin_ctz(m));                        // first accepted trial of the round
           found = true;
         } else {
-          const int left = o.max_ls - 1 - j0;                                // trials after j0: move on by 4, or to the last
-          const int adv = left < 4 ? left : 4;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) alpha = (i < adv) ? alpha * T(0.5) : alpha;
-          if (left < 4) break;                                               // alpha is now the last trial's step
+          const int left = o.max_ls - 1 - j0;                                // trials after j0: move on by G, or to the last
+          alpha = od_ldexp(alpha, -(left < G ? left : G));
+          if (left < G) break;                                               // alpha is now the last trial's step
         }
       }
       ls_trial<M>(th, pre, tr, z, D, alpha, r_vio, k_vio, zc, r, r_c, k_c);   // every copy lands on the chosen trial
