@@ -243,10 +243,10 @@ OD_HD bool eval_factor(const T* z, const T* th, const T* pre, const T* tr, T reg
 
 // backtracking on z - alpha D until either violation does not increase (at most max_ls trials, the last one is kept
 // regardless); leaves z at the accepted point, r = r(z; 0) and its violations.
-// Small models with lane copies (Opts::coop): a solve that jams spends most of its time here (acrobot at its joint
+// Models up to the hopper's size, when lanes carry copies (Opts::coop): a solve that jams spends most of its time here (acrobot at its joint
 // limit: ~15 trials in each of its 100 iterations), so after two sequential trials the 16/ppw copies each try a step
 // size, agree on the first accepted one (the same one the sequential loop would find) and re-evaluate it.
-template <class M> constexpr bool parallel_line_search() { return M::NZ <= 10; }
+template <class M> constexpr bool parallel_line_search() { return M::NZ <= 20; }
 
 template <class M, class T>
 OD_HD bool ls_trial(const T* th, const T* pre, T* tr, const T* z, const T* D, T alpha, T r_vio, T k_vio, T* zc, T* r, T& r_c, T& k_c) {
