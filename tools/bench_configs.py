@@ -1,6 +1,7 @@
 """Throughput of the other BASELINE.json configs on one MI355X (not the contract bench)."""
-import sys, time, json
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 import workloads as W, parity_checks as P
 import optimization_dynamics_amd as od
