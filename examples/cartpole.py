@@ -6,7 +6,9 @@ import sys
 
 import torch
 
-import optimization_dynamics_amd as od
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # run from anywhere
+import optimization_dynamics_amd as od  # noqa: E402
 from optimization_dynamics_amd import ilqr_al as iLQR
 
 
