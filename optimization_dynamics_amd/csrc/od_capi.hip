@@ -740,8 +740,8 @@ int od_model_indices(int model, int which, int* idx, int cap) {
     n = vt->nzq;
     for (int i = 0; i < n && i < 16; ++i) zq[i] = i;      // every model stores it first (csrc/gen/*.h: ZQ = 0..nzq-1)
     src = zq;
-  } else if (which == OD_IDX_GAMMA) { n = vt->ngam; src = vt->gam; }
-  else if (which == OD_IDX_B) { n = vt->nbfr; src = vt->bfr; }
+  } else if (which == OD_IDX_GAMMA) { n = vt->ngam; src = vt->gam.data(); }
+  else if (which == OD_IDX_B) { n = vt->nbfr; src = vt->bfr.data(); }
   else return fail(OD_ERR_INVALID, "od_model_indices: unknown index set");
   if (idx) for (int i = 0; i < n && i < cap; ++i) idx[i] = src[i];
   return n;

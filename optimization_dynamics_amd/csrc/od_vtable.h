@@ -1,6 +1,7 @@
 // Launch table: one entry per model, filled by the per-model translation units (od_model_*.hip)
 // so that the heavy template instantiations compile in parallel.
 #pragma once
+#include <array>
 #include <hip/hip_runtime.h>
 #include "od_units.h"
 
@@ -15,7 +16,8 @@ struct ModelVT {
   double r_tol, kappa_eval, kappa_grad, eps_min, kappa_reg, gamma_reg, undercut;
   int max_iter, max_ls;
   double fric_default[4];
-  int ngam, nbfr, gam[12], bfr[12];            // z indices of the impact / friction impulses
+  int ngam, nbfr;                              // z indices of the impact / friction impulses
+  std::array<int, 12> gam, bfr;
   hipError_t (*step_state)(const StepArgs<double>&, LaunchCfg, hipStream_t);        // pass 1, independent knots
   hipError_t (*rollout_state)(const RolloutArgs<double>&, LaunchCfg, hipStream_t);  // pass 1, rollouts
   hipError_t (*grad_knots)(const StepArgs<double>&, hipStream_t);                   // pass 2 (a.B knots)
@@ -25,6 +27,13 @@ struct ModelVT {
   hipError_t (*raw64)(const RawArgs<double>&, int ppw, hipStream_t);
   hipError_t (*raw32)(const RawArgs<float>&, int ppw, hipStream_t);
 };
+
+// first n entries of a generated index table, zero-padded
+template <int N> constexpr std::array<int, 12> od_pad12(const int (&a)[N], int n) {
+  std::array<int, 12> r{};
+  for (int i = 0; i < n && i < 12 && i < N; ++i) r[i] = a[i];
+  return r;
+}
 
 const ModelVT* vt_acrobot_impact();
 const ModelVT* vt_acrobot_nominal();
