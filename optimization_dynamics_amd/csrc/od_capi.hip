@@ -316,6 +316,7 @@ StepArgs<double> step_args(od_handle_s* h, long B, long K, const void* x, const 
   a.iters = mkview<int>(iters, 2, K, L);
   a.zg.p = nullptr; a.zg.se = 0; a.zg.sb = 0;
   a.want_grad = want_grad;
+  a.merge_grad_status = 0;
   a.d_skip_q2 = 0;
   return a;
 }
@@ -356,7 +357,8 @@ int run_step(od_handle_s* h, const char* fn, long B, const void* x, const void* 
     e.want_grad = 0;
     OD_HIP(h->vt->step_state(e, cfg_of(h, B), h->stream));
     StepArgs<double> g = a;
-    g.d.p = nullptr; g.status.p = nullptr; g.iters.p = nullptr;
+    g.d.p = nullptr;
+    g.merge_grad_status = 1;
     g.opts.kappa_eval = g.opts.kappa_grad;
     OD_HIP(h->vt->step_state(g, cfg_of(h, B), h->stream));
   } else {

@@ -96,6 +96,7 @@ template <class T> struct StepArgs {
   View<int> iters;   // 2 per problem: iterations to kappa_eval / kappa_grad
   View<T> zg;        // workspace, nz+1 per problem: gradient iterate and clamp (pass 1 -> pass 2)
   int want_grad;
+  int merge_grad_status;   // 1: this is the separate grad solve of a non-fusable step: merge into status / iters[1]
   int d_skip_q2;     // 1: only rows nq..2nq of d are written (compact q3 output)
 };
 
@@ -151,8 +152,14 @@ OD_HD void knot_state(const StepArgs<T>& a, long k, const T* xin, const T* uin, 
 #pragma unroll
     for (int i = 0; i < nq; ++i) c.put(q3out[i]);
   }
-  if (a.status.ok()) a.status.at(0, k) = st;
-  if (a.iters.ok()) { auto c = a.iters.cursor(k); c.put(it[0]); c.put(it[1]); }
+  if (a.merge_grad_status) {
+    // the eval solve already wrote its bits: add GRAD_OK of this solve, keep FACTOR_OK only if both factorised
+    if (a.status.ok()) { const int e = a.status.at(0, k); a.status.at(0, k) = (e & ~OD_ST_FACTOR_OK) | (st & OD_ST_GRAD_OK) | (e & st & OD_ST_FACTOR_OK); }
+    if (a.iters.ok()) { auto c = a.iters.cursor(k); c.skip(1); c.put(it[1]); }
+  } else {
+    if (a.status.ok()) a.status.at(0, k) = st;
+    if (a.iters.ok()) { auto c = a.iters.cursor(k); c.put(it[0]); c.put(it[1]); }
+  }
 }
 
 // independent knots (od_step, od_step_grad pass 1)

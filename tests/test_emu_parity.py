@@ -86,6 +86,8 @@ def test_finite_undercut_runs_two_passes(oracle, emu_lib):
     assert np.abs(D.numpy() - Do).max() < 1e-6
     rel = W.grad_rel_err(np.concatenate([DX.numpy(), DU.numpy()], 1), np.concatenate([DXo, DUo], 1))
     assert np.median(rel) < 1e-9 and (rel < 1e-4).mean() > 0.98
+    # status / iterations merge the two solves: bit 1 from the eval solve, bit 2 from the grad solve
+    assert ((st.numpy() & 3) == 3).mean() > 0.98 and (it.numpy()[1] > 0).all() and (it.numpy()[1] <= it.numpy()[0]).mean() > 0.9
 
 
 def test_friction_vector_is_live(emu_lib):
