@@ -9,6 +9,7 @@ from ._lib import Library, ODError, Options, default_library  # noqa: F401
 from .dynamics import ImplicitDynamics, f, fu, fx, state_to_configuration  # noqa: F401
 from .gradient_bundle import GradientBundle, MInfo, f_gb, fu_gb, fx_gb, gradient_, gradient_batch  # noqa: F401
 from .ilqr import ILQR, QuadraticObjective  # noqa: F401
+from .interior_point import InteriorPoint  # noqa: F401
 from .ls import LeastSquares, update_  # noqa: F401
 from .models import (acrobot_impact, acrobot_nominal, cartpole_friction, cartpole_frictionless,  # noqa: F401
                      hopper, planarpush, rocket)

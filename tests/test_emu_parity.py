@@ -66,6 +66,14 @@ def test_step_full_contact_forces(oracle, emu_lib, name):
     P.check_step_full(oracle, emu_lib, "cpu", name, 48)
 
 
+def test_raw_interior_point_solve(oracle, emu_lib):
+    P.check_ip_solve(oracle, emu_lib, "cpu")
+
+
+def test_raw_interior_point_solve_f32(oracle, emu_lib):
+    P.check_ip_solve(oracle, emu_lib, "cpu", dtype=torch.float32)
+
+
 def test_soc_projection(oracle, emu_lib):
     P.check_soc_projection(oracle, emu_lib, "cpu", 48)
 
