@@ -82,6 +82,24 @@ class ImplicitDynamics:
         if self.device.type == "cuda":
             self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def set_timestep(self, h):
+        """sim.h of both simulators"""
+        self.h = float(h)
+        self.lib.check(self.lib.cdll.od_set_timestep(self._h, self.h))
+
+    def set_options(self, **kw):
+        """change solver options of the live handle (r_tol, kappa_eval_tol, kappa_grad_tol, max_iter, max_ls, eps_min,
+        kappa_reg, gamma_reg, undercut); returns the options now in force"""
+        for k, v in kw.items():
+            setattr(self.options, k, v)
+        self.lib.check(self.lib.cdll.od_set_options(self._h, C.byref(self.options)))
+        return self.get_options()
+
+    def get_options(self):
+        o = _lib.Options()
+        self.lib.check(self.lib.cdll.od_get_options(self._h, C.byref(o)))
+        return o
+
     def set_launch_config(self, ppw=0, waves_per_block=0):
         """launch tuning (0 / -1 = automatic), see od_set_launch_config"""
         self.lib.check(self.lib.cdll.od_set_launch_config(self._h, int(ppw), int(waves_per_block)))

@@ -397,3 +397,26 @@ def check_ip_solve(oracle, lib, device, dtype=torch.float64):
     assert ok.mean() > 0.95
     assert (z[:2] - Q3).abs().cpu().numpy()[:, ok].max() < 1e-9
     assert_grad_close(dz.cpu().numpy()[:, :5], G.cpu().numpy(), ok, "raw solve vs step_grad")
+
+
+def check_live_setters(lib, device):
+    """od_set_timestep / od_set_options / od_get_options / od_set_u_max act on the live handle"""
+    name = "cartpole_friction"
+    X, U = W.knots(name, 32, seed=77)
+    Xt, Ut = torch.tensor(X), torch.tensor(U)
+    im = make_im(name, lib, device)
+    D1 = im.step(Xt, Ut)[0].clone()
+    im.set_timestep(0.02)
+    m = models.BY_NAME[name]
+    im2 = dyn.ImplicitDynamics(m, 0.02, r_tol=1e-8, kappa_eval_tol=W.CONFIGS[name][1], kappa_grad_tol=W.CONFIGS[name][2], device=device, lib=lib)
+    D2, D3 = im.step(Xt, Ut)[0], im2.step(Xt, Ut)[0]
+    assert torch.equal(D2, D3) and (D1 - D2).abs().max().item() > 1e-4
+    o = im.set_options(max_iter=3, kappa_eval_tol=1e-2)
+    assert o.max_iter == 3 and o.kappa_eval_tol == 1e-2 and o.r_tol == 1e-8
+    D, st, it = im.step(Xt, Ut)
+    assert (it[0] <= 3).all()
+    info = rk.RocketInfo(models.rocket, 12.5, 0.05, device=device, lib=lib)
+    u = torch.tensor([[0.0], [0.0], [20.0]])
+    assert abs(info.project(u, grads=False)[0][2, 0].item() - 12.5) < 2e-3
+    info.lib.check(info.lib.cdll.od_set_u_max(info._h, 5.0))
+    assert abs(info.project(u, grads=False)[0][2, 0].item() - 5.0) < 2e-3

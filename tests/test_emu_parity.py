@@ -74,6 +74,10 @@ def test_raw_interior_point_solve_f32(oracle, emu_lib):
     P.check_ip_solve(oracle, emu_lib, "cpu", dtype=torch.float32)
 
 
+def test_live_setters(emu_lib):
+    P.check_live_setters(emu_lib, "cpu")
+
+
 def test_soc_projection(oracle, emu_lib):
     P.check_soc_projection(oracle, emu_lib, "cpu", 48)
 
