@@ -156,11 +156,37 @@ template <class M, class T> OD_HD T soc_step_coop(const T* z, const T* D, T tau,
     }
     a = od_min(a, soc_step_one<n>(lam, dl, tau));
   }
-  return coop_min4(a, ppw);
+  return a;                    // this copy's share: the caller combines the four copies
+}
+
+// The 2*NORT orthant ratio tests shared out the same way: copy g takes tests g, g+4, ... and returns its own minimum.
+template <class M, class T> OD_HD T ort_step_coop(const T* z, const T* D, T tau, int ppw) {
+  constexpr int NT = 2 * M::NORT;
+  const int g = coop_group(ppw);
+  T num = T(1), den = T(1);
+#pragma unroll
+  for (int r0 = 0; r0 < NT; r0 += 4) {
+    auto idx = [](int t) constexpr { t = t < NT ? t : NT - 1; return (t & 1) ? M::ORT2[t >> 1] : M::ORT1[t >> 1]; };   // past the end: repeat
+    const int k0 = idx(r0), k1 = idx(r0 + 1), k2 = idx(r0 + 2), k3 = idx(r0 + 3);
+    const T zk = coop_pick(g, z[k0], z[k1], z[k2], z[k3]), dk = coop_pick(g, D[k0], D[k1], D[k2], D[k3]);
+    const T n1 = tau * zk;
+    if (dk > T(0) && n1 * den < num * dk) { num = n1; den = dk; }
+  }
+  return num * od_rcp(den);
 }
 
 // largest alpha in (0,1] keeping z - alpha*D inside the cones (fractions tau_ort / tau_soc)
 template <class M, class T> OD_HD T step_length(const T* z, const T* D, T tau_ort, T tau_soc, int coop) {
+  constexpr bool COOP_OK = (M::NSOC == 0) || soc_uniform<M>();
+  if constexpr (COOP_OK && (M::NORT + M::NSOC) > 0) {
+    if (coop) {
+      // every copy of the problem does a quarter of the tests; one combine for orthant and cone tests together
+      T a = T(1);
+      if constexpr (M::NORT > 0) a = ort_step_coop<M>(z, D, tau_ort, coop);
+      if constexpr (M::NSOC > 0) a = od_min(a, soc_step_coop<M>(z, D, tau_soc, coop));
+      return coop_min4(a, coop);
+    }
+  }
   T a = T(1);
   if constexpr (M::NORT > 0) {
     // min over the ratio tests tau*z_k/D_k (D_k > 0) kept as a fraction: one reciprocal at the end
@@ -174,12 +200,7 @@ template <class M, class T> OD_HD T step_length(const T* z, const T* D, T tau_or
     }
     a = num * od_rcp(den);
   }
-  if constexpr (M::NSOC > 0) {
-    if constexpr (soc_uniform<M>()) {
-      if (coop) return od_min(a, soc_step_coop<M>(z, D, tau_soc, coop));
-    }
-    a = soc_step_cone<M, 0>(z, D, tau_soc, a);
-  }
+  if constexpr (M::NSOC > 0) a = soc_step_cone<M, 0>(z, D, tau_soc, a);
   return a;
 }
 
