@@ -164,7 +164,112 @@ struct IlqrArgs {
   View<double> dV;                                   // per trajectory: [sum k'Qu, sum 0.5 k'Quu k]
   View<int> status;                                  // per trajectory: 1 = every Quu factorised (positive pivots)
 };
-__global__ __launch_bounds__(OD_BLOCK) void k_ilqr_backward(IlqrArgs a) {
+#if defined(__HIPCC__)
+// One 256-thread workgroup per trajectory, matrices in LDS, thread (i, j) = tid % rows, tid / rows owns one entry of
+// each small product (n <= 16: n*n <= 256 entries).  The first version ran one LANE per trajectory with dynamically
+// indexed private arrays (scratch): 53 ms per call for the rocket (n = 12, m = 3, T = 60, 4096 trajectories) -- 77 % of an
+// iLQR iteration; this one: see profiles/r1_ilqr.json.
+constexpr int OD_IL_THREADS = 256;
+__global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward(IlqrArgs a) {
+  const long b = blockIdx.x;
+  const int n = a.n, m = a.m, tid = threadIdx.x;
+  __shared__ double Vxx[OD_IL_N * OD_IL_N], At[OD_IL_N * OD_IL_N], W[OD_IL_N * OD_IL_N], Qxx[OD_IL_N * OD_IL_N];
+  __shared__ double Bt[OD_IL_N * OD_IL_M], WB[OD_IL_N * OD_IL_M], Qux[OD_IL_M * OD_IL_N], Kt[OD_IL_M * OD_IL_N], QK[OD_IL_M * OD_IL_N];
+  __shared__ double Quu[OD_IL_M * OD_IL_M], L[OD_IL_M * OD_IL_M];
+  __shared__ double Vx[OD_IL_N], Qx[OD_IL_N], Qu[OD_IL_M], kt[OD_IL_M], Quuk[OD_IL_M];
+  __shared__ double dV[2];
+  __shared__ int okflag;
+  const int nn = n * n, nm = n * m, mm = m * m;
+  // entry owned by this thread in n x n, n x m (rows n) and m x n (rows m) matrices
+  const int in_ = tid % n, jn_ = tid / n;         // valid if tid < nn (n x n) or tid < nm (n x m: column jn_ < m)
+  const int im_ = tid % m, jm_ = tid / m;         // valid if tid < nm (m x n: column jm_ < n) or tid < mm (m x m)
+  if (tid < nn) Vxx[tid] = a.VxxT.at(tid, b);
+  if (tid < n) Vx[tid] = a.VxT.at(tid, b);
+  if (tid == 0) { dV[0] = 0.0; dV[1] = 0.0; okflag = 1; }
+  __syncthreads();
+  for (int t = a.T - 1; t >= 0; --t) {
+    const long kk = (long)t * a.B + b;
+    if (tid < nn) At[tid] = a.A.at(tid, kk);
+    if (tid < nm) Bt[tid] = a.Bm.at(tid, kk);
+    __syncthreads();
+    // W = Vxx A (n x n), WB = Vxx B (n x m)
+    if (tid < nn) { double s = 0; for (int l = 0; l < n; ++l) s += Vxx[in_ + n * l] * At[l + n * jn_]; W[tid] = s; }
+    if (tid < nm) { double s = 0; for (int l = 0; l < n; ++l) s += Vxx[in_ + n * l] * Bt[l + n * jn_]; WB[tid] = s; }
+    __syncthreads();
+    // Qxx = lxx + A'W, Qux = lux + B'W, Quu = luu + B'WB, Qx = lx + A'Vx, Qu = lu + B'Vx
+    if (tid < nn) { double s = a.lxx.at(tid, kk); for (int l = 0; l < n; ++l) s += At[l + n * in_] * W[l + n * jn_]; Qxx[tid] = s; }
+    if (tid < nm) { double s = a.lux.at(tid, kk); for (int l = 0; l < n; ++l) s += Bt[l + n * im_] * W[l + n * jm_]; Qux[tid] = s; }
+    if (tid < mm) { double s = a.luu.at(tid, kk); for (int l = 0; l < n; ++l) s += Bt[l + n * im_] * WB[l + n * jm_]; Quu[tid] = s; }
+    if (tid < n) { double s = a.lx.at(tid, kk); for (int l = 0; l < n; ++l) s += At[l + n * tid] * Vx[l]; Qx[tid] = s; }
+    if (tid < m) { double s = a.lu.at(tid, kk); for (int l = 0; l < n; ++l) s += Bt[l + n * tid] * Vx[l]; Qu[tid] = s; }
+    __syncthreads();
+    // Cholesky of Quu + reg I (m <= 12: one thread)
+    if (tid == 0) {
+      for (int i = 0; i < mm; ++i) L[i] = Quu[i];
+      for (int i = 0; i < m; ++i) L[i + m * i] += a.reg;
+      for (int j = 0; j < m; ++j) {
+        double d = L[j + m * j];
+        for (int l = 0; l < j; ++l) d -= L[j + m * l] * L[j + m * l];
+        if (!(d > 0.0)) { okflag = 0; d = 1e-12; }
+        d = sqrt(d);
+        L[j + m * j] = d;
+        for (int i = j + 1; i < m; ++i) { double sx = L[i + m * j]; for (int l = 0; l < j; ++l) sx -= L[i + m * l] * L[j + m * l]; L[i + m * j] = sx / d; }
+      }
+    }
+    __syncthreads();
+    // K = -(Quu+reg)^{-1} Qux (one thread per column), k = -(Quu+reg)^{-1} Qu (thread n)
+    if (tid <= n) {
+      const int c = tid;
+      double y[OD_IL_M];
+      for (int i = 0; i < m; ++i) y[i] = (c < n) ? Qux[i + m * c] : Qu[i];
+      for (int i = 0; i < m; ++i) { double sx = y[i]; for (int l = 0; l < i; ++l) sx -= L[i + m * l] * y[l]; y[i] = sx / L[i + m * i]; }
+      for (int i = m - 1; i >= 0; --i) { double sx = y[i]; for (int l = i + 1; l < m; ++l) sx -= L[l + m * i] * y[l]; y[i] = sx / L[i + m * i]; }
+      for (int i = 0; i < m; ++i) { if (c < n) Kt[i + m * c] = -y[i]; else kt[i] = -y[i]; }
+    }
+    __syncthreads();
+    if (tid < nm) a.K.at(tid, kk) = Kt[tid];
+    if (tid < m) {
+      a.k.at(tid, kk) = kt[tid];
+      double sx = 0; for (int l = 0; l < m; ++l) sx += Quu[tid + m * l] * kt[l];
+      Quuk[tid] = sx;                                             // Quu k (Quu without reg, as in the cost-to-go expansion)
+    }
+    // QK = Quu K (m x n)
+    if (tid < nm) { double sx = 0; for (int l = 0; l < m; ++l) sx += Quu[im_ + m * l] * Kt[l + m * jm_]; QK[tid] = sx; }
+    __syncthreads();
+    if (tid == 0) {
+      double d1 = 0, d2 = 0;
+      for (int i = 0; i < m; ++i) { d1 += kt[i] * Qu[i]; d2 += 0.5 * kt[i] * Quuk[i]; }
+      dV[0] += d1; dV[1] += d2;
+    }
+    // value function update
+    double vx_new = 0, vxx_new = 0;
+    if (tid < n) {
+      double sx = Qx[tid];
+      for (int l = 0; l < m; ++l) sx += Kt[l + m * tid] * (Quuk[l] + Qu[l]) + Qux[l + m * tid] * kt[l];
+      vx_new = sx;
+    }
+    if (tid < nn) {
+      double sx = Qxx[tid];
+      for (int l = 0; l < m; ++l) sx += Kt[l + m * in_] * (QK[l + m * jn_] + Qux[l + m * jn_]) + Qux[l + m * in_] * Kt[l + m * jn_];
+      vxx_new = sx;
+    }
+    __syncthreads();
+    if (tid < n) Vx[tid] = vx_new;
+    if (tid < nn) Vxx[tid] = vxx_new;
+    __syncthreads();
+    if (tid < nn && in_ < jn_) { const double sx = 0.5 * (Vxx[in_ + n * jn_] + Vxx[jn_ + n * in_]); Vxx[in_ + n * jn_] = sx; Vxx[jn_ + n * in_] = sx; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    a.dV.at(0, b) = dV[0];
+    a.dV.at(1, b) = dV[1];
+    if (a.status.ok()) a.status.at(0, b) = okflag;
+  }
+}
+
+#else
+// host test build (threads run one after the other, no workgroup cooperation): one lane per trajectory
+__global__ __launch_bounds__(OD_BLOCK) void k_ilqr_backward_serial(IlqrArgs a) {
   const long b = (long)blockIdx.x * OD_BLOCK + threadIdx.x;
   if (b >= a.B) return;
   const int n = a.n, m = a.m;
@@ -231,6 +336,8 @@ __global__ __launch_bounds__(OD_BLOCK) void k_ilqr_backward(IlqrArgs a) {
   a.dV.at(1, b) = dV2;
   if (a.status.ok()) a.status.at(0, b) = ok ? 1 : 0;
 }
+
+#endif
 
 }  // namespace
 
@@ -671,7 +778,11 @@ int od_ilqr_backward(od_handle h, long B, int T, int n, int m, const void* A, co
   a.VxxT = mkcview<double>(VxxT, n * n, B, L); a.VxT = mkcview<double>(VxT, n, B, L);
   a.K = mkview<double>(K, m * n, Kn, L); a.k = mkview<double>(k, m, Kn, L);
   a.dV = mkview<double>(dV, 2, B, L); a.status = mkview<int>(status, 1, B, L);
-  hipLaunchKernelGGL(k_ilqr_backward, od_grid(B, OD_BLOCK), dim3(OD_BLOCK), 0, h->stream, a);
+#if defined(__HIPCC__)
+  hipLaunchKernelGGL(k_ilqr_backward, dim3((unsigned)B), dim3(OD_IL_THREADS), 0, h->stream, a);
+#else
+  hipLaunchKernelGGL(k_ilqr_backward_serial, od_grid(B, OD_BLOCK), dim3(OD_BLOCK), 0, h->stream, a);
+#endif
   OD_HIP(hipGetLastError());
   return OD_OK;
 }
