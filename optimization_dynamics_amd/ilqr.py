@@ -39,9 +39,13 @@ class QuadraticObjective:
     def value(self, X, U, lam=None, rho=0.0):
         """X: (n, T+1, P), U: (m, T, P) -> cost per trajectory (P,)"""
         dx = X - self.x_ref[:, None, None]
-        J = 0.5 * torch.einsum("itp,ij,jtp->p", dx[:, :-1], self.Q, dx[:, :-1])
-        J = J + 0.5 * torch.einsum("itp,ij,jtp->p", U, self.R, U)
-        J = J + 0.5 * torch.einsum("ip,ij,jp->p", dx[:, -1], self.QT, dx[:, -1])
+        T, P = U.shape[1], U.shape[2]
+
+        def quad(M, v):                     # sum over knots of 1/2 v'Mv per trajectory: one skinny GEMM, not an einsum
+            vf = v.reshape(v.shape[0], -1)
+            return 0.5 * (vf * (M @ vf)).sum(0).view(-1, P).sum(0)
+
+        J = quad(self.Q, dx[:, :-1]) + quad(self.R, U) + quad(self.QT, dx[:, -1])
         if self.goal_idx is not None and lam is not None:
             c = self.constraint(X)
             J = J + (lam * c).sum(0) + 0.5 * rho * (c * c).sum(0)
