@@ -72,7 +72,20 @@ def cpu_baseline(batch, horizon, seed, budget_s=12.0):
     t0 = time.time()
     _, _, _, bad = O.rollout(sim, x1[:, :nb2], U[:, :, :nb2])
     dt = time.time() - t0
-    return dict(value=nb2 * horizon / dt, unit="steps+grads/s", cores=cores, kind="port",
+    # the same code on one thread (single-thread and all-cores figures)
+    single = None
+    try:
+        import ctypes
+        omp = ctypes.CDLL("libgomp.so.1")
+        omp.omp_set_num_threads(1)
+        ns = min(batch, 8)
+        t1 = time.time()
+        O.rollout(sim, x1[:, :ns], U[:, :, :ns])
+        single = ns * horizon / (time.time() - t1)
+        omp.omp_set_num_threads(cores)
+    except Exception:
+        pass
+    return dict(value=nb2 * horizon / dt, unit="steps+grads/s", cores=cores, kind="port", single_thread_value=single,
                 sample="%d of %d trajectories x T=%d (same seed), %.1f s, OpenMP over trajectories; "
                        "CPU restatement of the reference algorithm (f, fx, fu = 3 dense-LU IP solves per knot), "
                        "not the Julia reference" % (nb2, batch, horizon, dt),
