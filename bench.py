@@ -54,12 +54,40 @@ def make_inputs(batch, horizon, seed, h=0.05):
     return x1, U
 
 
+def effective_cores():
+    """host cores this process may actually use: CPU count, affinity mask and the cgroup CPU quota (a container on a
+    256-thread box can be limited to 16 CPUs' worth of time; 256 OpenMP threads would only be throttled)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(batch, horizon, seed, budget_s=12.0):
     """Oracle (CPU restatement: three dense-LU solves per knot like the reference) on a bounded
     sample of the same workload, OpenMP over trajectories on all host cores."""
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cores = effective_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    try:                                     # the runtime may already be initialised: set the team size explicitly too
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except Exception:
+        pass
     sim = O.make_sim("hopper", 0.05, kappa_tol=1e-4, kappa_grad_tol=1e-3)
     x1, U = make_inputs(batch, horizon, seed)
     nb = min(batch, max(cores, 16))
@@ -69,8 +97,12 @@ def cpu_baseline(batch, horizon, seed, budget_s=12.0):
     rate = nb * horizon / dt
     nb2 = int(min(batch, max(nb, rate * budget_s / horizon)))
     nb2 = max(cores, (nb2 // cores) * cores)
+    bufs = {}
+    xs, Us = np.asfortranarray(x1[:, :nb2]), np.asfortranarray(U[:, :, :nb2])
+    O.rollout(sim, xs[:, :cores], Us[:, :, :cores])                     # threads up
+    X_, A_, B_, bad = O.rollout(sim, xs, Us, bufs=bufs)                 # output arrays allocated and touched
     t0 = time.time()
-    _, _, _, bad = O.rollout(sim, x1[:, :nb2], U[:, :, :nb2])
+    _, _, _, bad = O.rollout(sim, xs, Us, bufs=bufs)                    # timed: the solves only, like the GPU side
     dt = time.time() - t0
     # the same code on one thread (single-thread and all-cores figures)
     single = None

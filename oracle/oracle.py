@@ -224,16 +224,22 @@ def step_grad_batch(sim, X, U):
     return D.reshape(n, B, order="F"), DX.reshape(n, n, B, order="F"), DU.reshape(n, nu, B, order="F"), bad
 
 
-def rollout(sim, x1, U, grads=True):
-    """x1: (2nq,B); U: (nu,T,B) -> X (2nq,T+1,B), A (2nq,2nq,T,B), Bm (2nq,nu,T,B), nbad"""
+def rollout(sim, x1, U, grads=True, bufs=None):
+    """x1: (2nq,B); U: (nu,T,B) -> X (2nq,T+1,B), A (2nq,2nq,T,B), Bm (2nq,nu,T,B), nbad.
+    `bufs` (a dict, filled on first use) lets a caller time the solves without the page faults of fresh output arrays."""
     d = dims(sim.model_id)
     n, nu = 2 * d["nq"], d["nu"]
     x1 = np.asfortranarray(x1, dtype=np.float64)
     U = np.asfortranarray(U, dtype=np.float64)
     T, B = U.shape[1], U.shape[2]
-    X = np.zeros(n * (T + 1) * B)
-    A = np.zeros(n * n * T * B) if grads else None
-    Bm = np.zeros(n * nu * T * B) if grads else None
+    if bufs is not None and bufs.get("shape") == (n, nu, T, B, grads):
+        X, A, Bm = bufs["X"], bufs["A"], bufs["Bm"]
+    else:
+        X = np.zeros(n * (T + 1) * B)
+        A = np.zeros(n * n * T * B) if grads else None
+        Bm = np.zeros(n * nu * T * B) if grads else None
+        if bufs is not None:
+            bufs.update(shape=(n, nu, T, B, grads), X=X, A=A, Bm=Bm)
     bad = lib().od_oracle_rollout(C.byref(sim), B, T, _p(x1.reshape(-1, order="F")), _p(U.reshape(-1, order="F")), _p(X), _p(A), _p(Bm))
     X = X.reshape(n, T + 1, B, order="F")
     if grads:
