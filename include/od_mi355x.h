@@ -92,7 +92,10 @@ int od_step(od_handle h, long B, const void* x, const void* u, void* d, int* sta
 /* f + fx + fu (src/dynamics.jl:81-128) with one interior-point solve per knot (two launches: the solves,
  * then all implicit-function gradients; the handle owns the hand-over workspace).  dx: 2nq x 2nq, du: 2nq x nu per
  * problem, every entry written (the reference writes 3 blocks into a caller-zeroed matrix).
- * Any of d, dx, du may be NULL. */
+ * Any of d, dx, du may be NULL.  status: OD_STATUS_EVAL_OK = state converged at kappa_eval, OD_STATUS_GRAD_OK = gradient
+ * iterate converged at kappa_grad, OD_STATUS_FACTOR_OK = no pivot vanished.  With a finite undercut (and cones, and
+ * kappa_eval != kappa_grad) the two simulators of the reference iterate differently: the library then runs two
+ * solves per knot like the reference and merges their status bits and iteration counts. */
 int od_step_grad(od_handle h, long B, const void* x, const void* u, void* d, void* dx, void* du,
                  int* status, int* iters);
 
