@@ -419,6 +419,8 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
             % (len(m.ort[0]), len(m.soc), max_soc, len(m.equr), len(m.bil), len(m.idx_zq)))
     o.write("  static constexpr bool REG_POSTHOC = %s;\n" % ("true" if d.reg_posthoc else "false"))
     o.write("  static constexpr int NFACT = %d, MTAIL = %d, TAIL_BASE = %d, NSWAP = %d;\n" % (el.slots, el.m, el.tail_base, len(el.swaps)))
+    o.write("  // the interior-point iterations may factor the tail without runtime pivoting (gradient solves always pivot)\n")
+    o.write("  static constexpr bool STATIC_TAIL = %s;\n" % ("true" if (m.static_tail and el.m > 0) else "false"))
     o.write(arr("ORT1", m.ort[0]) + arr("ORT2", m.ort[1]) + arr("ORTR", m.ortr))
     o.write(arr("SOCOFF", soc_off) + arr("SOC1", soc_flat_p) + arr("SOC2", soc_flat_d) + arr("SOCR", socr_flat))
     o.write(arr("EQUR", m.equr) + arr("BIL", m.bil) + arr("ZQ", m.idx_zq))
@@ -596,7 +598,7 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
     o.write("  template <class T> struct Fact { T v[NFACT > 0 ? NFACT : 1]; int piv[MTAIL > 0 ? MTAIL : 1]; bool sw[NSWAP > 0 ? NSWAP : 1]; };\n\n")
     o.write("  // statically ordered sparse elimination (%d pivots) + %dx%d runtime-pivoted dense tail\n"
             % (len(m.elim), el.m, el.m))
-    o.write("  template <class T, class F> OD_HD static bool factor(const T* a, F& f) {\n")
+    o.write("  template <bool PIV = true, class T, class F> OD_HD static bool factor(const T* a, F& f) {\n")
     for k, (i, j) in enumerate(d.rz_nz):
         o.write("    T a_%d_%d = a[%d];\n" % (i, j, k))
     fills = sorted(el.final_pattern - set(d.rz_nz))
@@ -620,7 +622,7 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
             else:
                 o.write("    tl_[%d] = T(0);\n" % (ii + el.m * jj))
     if el.m > 0:
-        o.write("    const bool ok_ = od_lu_factor<T, MTAIL>(tl_, f.piv);\n")
+        o.write("    bool ok_;\n    if constexpr (PIV) ok_ = od_lu_factor<T, MTAIL>(tl_, f.piv);\n    else ok_ = od_lu_factor_static<T, MTAIL>(tl_);\n")
         o.write("#pragma unroll\n    for (int i = 0; i < MTAIL * MTAIL; ++i) f.v[TAIL_BASE + i] = tl_[i];\n")
         o.write("    return ok_;\n")
     else:
@@ -629,7 +631,7 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
 
     # ---- solve ----
     o.write("  // x = rz^{-1} b using the stored factors (b and x may alias)\n")
-    o.write("  template <class T, class F> OD_HD static void solve(const F& f, const T* b, T* x) {\n")
+    o.write("  template <bool PIV = true, class T, class F> OD_HD static void solve(const F& f, const T* b, T* x) {\n")
     for i in range(m.nz):
         o.write("    T y_%d = b[%d];\n" % (i, i))
     for k, ((ra, rb), (ca, cb)) in enumerate(el.swaps):
@@ -654,7 +656,8 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
         o.write("    T t_[MTAIL];\n")
         for ii, i in enumerate(el.tail_rows):
             o.write("    t_[%d] = y_%d;\n" % (ii, i))
-        o.write("    od_lu_solve<T, MTAIL>(od_tail_view<T, TAIL_BASE>(f), f.piv, t_);\n")
+        o.write("    if constexpr (PIV) od_lu_solve<T, MTAIL>(od_tail_view<T, TAIL_BASE>(f), f.piv, t_);\n")
+        o.write("    else od_lu_solve_static<T, MTAIL>(od_tail_view<T, TAIL_BASE>(f), t_);\n")
         for jj, j in enumerate(el.tail_cols):
             o.write("    const T x_%d = t_[%d];\n" % (j, jj))
     for (prw, pc, ipval, us) in reversed(el.bwd):

@@ -63,6 +63,10 @@ class ModelSpec:
     # runtime role swaps for second-order-cone blocks: ((row_a,row_b),(col_a,col_b)); rows/cols are
     # exchanged when |A[row_a,col_b]| > |A[row_b,col_a]| (psi vs s_psi: sticking vs sliding mode)
     swaps: List[Tuple[Tuple[int, int], Tuple[int, int]]] = field(default_factory=list)
+    # the dense tail may be factored without runtime pivoting inside the interior-point iterations (measured per
+    # model against the pivoted factorisation: identical iteration counts and iterates); the implicit-gradient solve
+    # at the converged point always pivots
+    static_tail: bool = False
     # default solver options (reference src/dynamics.jl:25-33 etc.)
     opts: Dict[str, float] = field(default_factory=dict)
     notes: str = ""
@@ -532,6 +536,7 @@ def hopper() -> ModelSpec:
         idx_zq=[0, 1, 2, 3], idx_gamma=[4, 5, 6, 7], idx_b=[14, 15],
         elim=elim, floor_pivots=[(12 + i, 4 + i) for i in range(4)],
         swaps=[((16, 17), (14, 16)), ((18, 19), (15, 17))],
+        static_tail=True,
         opts=dict(IP_DEFAULT, kappa_tol=1e-4, kappa_grad_tol=1e-3),       # examples/hopper.jl:42
         notes="RoboDojo hopper, restated from recall; constants unverified",
     )

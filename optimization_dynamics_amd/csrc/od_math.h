@@ -202,6 +202,29 @@ template <class T, int N> OD_HD bool od_lu_factor(T* A, int* piv) {
   return ok;
 }
 
+// The same factorisation with the pivots taken down the diagonal, in the generated order (no search, no exchange,
+// nothing to replay in the solves).  For models whose tail needs no runtime pivoting in the interior-point
+// iterations (M::STATIC_TAIL: measured per model against the pivoted factorisation -- the hopper's iterates are
+// identical, its converged-point gradient solve is NOT and keeps od_lu_factor).
+template <class T, int N> OD_HD bool od_lu_factor_static(T* A) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    ok = ok && (od_abs(A[k + N * k]) > T(0));
+    const T inv = od_rcp(A[k + N * k]);
+    A[k + N * k] = inv;
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) A[i + N * k] *= inv;
+#pragma unroll
+    for (int j = k + 1; j < N; ++j) {
+      const T ukj = A[k + N * j];
+#pragma unroll
+      for (int i = k + 1; i < N; ++i) A[i + N * j] -= A[i + N * k] * ukj;
+    }
+  }
+  return ok;
+}
+
 // read-only view of the tail block inside a factor store (registers or any other storage with v[i])
 template <class T, int BASE, class F> struct TailView {
   const F& f;
@@ -222,6 +245,20 @@ template <class T, int N, class Mat> OD_HD void od_lu_solve(const Mat& A, const 
     }
 #pragma unroll
     for (int i = k + 1; i < N; ++i) b[i] -= A[i + N * k] * b[k];   // ... then its elimination step
+  }
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {
+    b[k] *= A[k + N * k];
+#pragma unroll
+    for (int i = 0; i < k; ++i) b[i] -= A[i + N * k] * b[k];
+  }
+}
+
+template <class T, int N, class Mat> OD_HD void od_lu_solve_static(const Mat& A, T* b) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) b[i] -= A[i + N * k] * b[k];
   }
 #pragma unroll
   for (int k = N - 1; k >= 0; --k) {

@@ -245,7 +245,8 @@ template <class M, int C, class T> OD_HD void correction_cone(T* r, const T* Da)
 
 // rz evaluated with the orthant variables clamped from below at reg (regularisation of
 // rz!(ip, rz, z, theta; reg)), then factored.
-template <class M, class T, class F>
+// PIV = false: the tail is factored down its diagonal (models with M::STATIC_TAIL, interior-point iterations only)
+template <class M, bool PIV = true, class T, class F>
 OD_HD bool eval_factor(const T* z, const T* th, const T* pre, const T* tr, T reg, F& f) {
   T zr[M::NZ];
 #pragma unroll
@@ -259,7 +260,7 @@ OD_HD bool eval_factor(const T* z, const T* th, const T* pre, const T* tr, T reg
   }
   T a[M::NNZ];
   M::eval_rz(zr, th, pre, tr, a);
-  return M::factor(a, f);
+  return M::template factor<PIV>(a, f);
 }
 
 // backtracking on z - alpha D until either violation does not increase (at most max_ls trials, the last one is kept
@@ -327,9 +328,10 @@ OD_HD void ip_iteration(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z
   constexpr bool CONES = (M::NORT + M::NSOC) > 0;
   const T reg = (k_vio < o.kappa_reg) ? k_vio * o.gamma_reg : T(0);
   reg_prev = reg;
-  if (!eval_factor<M>(z, th, pre, tr, reg, f)) status &= ~OD_ST_FACTOR_OK;
+  constexpr bool PIV = !M::STATIC_TAIL;
+  if (!eval_factor<M, PIV>(z, th, pre, tr, reg, f)) status &= ~OD_ST_FACTOR_OK;
   T D[M::NZ];
-  M::solve(f, r, D);                                   // affine (predictor) direction
+  M::template solve<PIV>(f, r, D);                     // affine (predictor) direction
   if constexpr (CONES) {
     const T aaff = step_length<M>(z, D, T(1), T(1), o.coop);
     T kap = centering_kappa<M>(z, D, aaff);
@@ -341,7 +343,7 @@ OD_HD void ip_iteration(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z
       for (int i = 0; i < M::NORT; ++i) r[M::ORTR[i]] += D[M::ORT1[i]] * D[M::ORT2[i]];
     }
     if constexpr (M::NSOC > 0) correction_cone<M, 0>(r, D);
-    M::solve(f, r, D);                                 // corrector direction, factors reused
+    M::template solve<PIV>(f, r, D);                   // corrector direction, factors reused
   }
   const T vio = od_max(r_vio, k_vio);
   const T tau = T(1) - od_min(o.eps_min, vio * vio);
