@@ -83,6 +83,10 @@ int od_set_stream(od_handle h, void* hip_stream);
  * -- a wavefront is as slow as its slowest lane, so small batches are spread over more wavefronts.
  * waves_per_block: 1 or 4 wavefronts per workgroup (4 = one per SIMD of a CU), 0 = automatic. */
 int od_set_launch_config(od_handle h, int ppw, int waves_per_block);
+/* cooperative solve pass (one problem per 16 lanes, the contacts / cones of a problem spread over them): shortens the
+ * critical path of small batches.  mode 0 = automatic (batches that leave lanes idle, models that have the kernels),
+ * 1 = never, 2 = always where the model has them.  Results agree with the lane-per-problem kernels to rounding. */
+int od_set_cooperative(od_handle h, int mode);
 int od_synchronize(od_handle h);
 
 /* f (src/dynamics.jl:81-94) for B knots: d = [q2; q3].  x: 2nq, u: nu, d: 2nq per problem.

@@ -51,6 +51,7 @@ SIGNATURES = {
     "od_set_layout": (C.c_int, [_VP, C.c_int]),
     "od_set_stream": (C.c_int, [_VP, _VP]),
     "od_set_launch_config": (C.c_int, [_VP, C.c_int, C.c_int]),
+    "od_set_cooperative": (C.c_int, [_VP, C.c_int]),
     "od_synchronize": (C.c_int, [_VP]),
     "od_step": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _IP, _IP]),
     "od_step_grad": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _VP, _VP, _IP, _IP]),

@@ -3,6 +3,7 @@ import os
 import sys
 import time
 
+from .coop import emit_coop
 from .emit import Derived, emit_device, emit_oracle, emit_oracle_table, stats
 from .models import ALL_MODELS
 
@@ -28,6 +29,14 @@ def main(argv):
         with open(os.path.join(ora_dir, name + ".h"), "w") as f:
             f.write(emit_oracle(m, d))
             f.write(emit_oracle_table(m))
+        # cooperative (16 lanes per problem) solver glue, for the models whose block structure allows it
+        coop = emit_coop(m, d)
+        coop_path = os.path.join(dev_dir, "coop_" + name + ".h")
+        if coop is not None:
+            with open(coop_path, "w") as f:
+                f.write(coop)
+        elif os.path.exists(coop_path):
+            os.remove(coop_path)
         all_stats[name] = stats(m, d)
         print("%-24s %6.1fs  %s" % (name, time.time() - t0, all_stats[name]), flush=True)
     json.dump(all_stats, open(stats_path, "w"), indent=1, sort_keys=True)

@@ -349,6 +349,7 @@ struct od_handle_s {
   hipStream_t stream;
   int ppw;         // problems per wavefront; 0 = automatic (od_auto_ppw)
   int wpb;         // wavefronts per workgroup of the state pass: 0 automatic, 1 or 4
+  int coop;        // cooperative state kernels (od_coop.h): 0 automatic, 1 never, 2 wherever the model has them
   double* work;    // device workspace: gradient iterates handed from pass 1 to pass 2
   size_t work_elems;
   double* stage;   // device staging for the host scalar path
@@ -376,10 +377,15 @@ int ppw_of(const od_handle_s* h, long n) { return h->ppw > 0 ? h->ppw : od_auto_
 
 // pass-1 launch shape: 4 wavefronts per workgroup (one per SIMD) while that still spreads the batch over
 // the chip, problems per wavefront from od_auto_ppw (aims at one resident wavefront per SIMD)
+// The cooperative kernels put one problem on 16 lanes (4 per wavefront): they shorten the critical path of a problem
+// and pay off while the batch leaves lanes idle -- up to OD_COOP_AUTO_MAX problems (one 4-problem wavefront per SIMD);
+// larger batches fill the lanes with whole problems instead.
+constexpr long OD_COOP_AUTO_MAX = 4096;
 LaunchCfg cfg_of(const od_handle_s* h, long n) {
   LaunchCfg c;
   c.ppw = ppw_of(h, n);
   c.wpb = h->wpb > 0 ? h->wpb : 4;
+  c.coop = h->vt->has_coop && (h->coop == 2 || (h->coop == 0 && h->ppw == 0 && n <= OD_COOP_AUTO_MAX));
   return c;
 }
 
@@ -621,6 +627,7 @@ int od_create(int model, int dtype, const od_options* opts, double dt, od_handle
   h->u_max = 12.5;   // examples/rocket.jl:16
   h->stream = nullptr;
   h->ppw = 0;
+  h->coop = 0;
   h->wpb = 0;
   h->work = nullptr;
   h->work_elems = 0;
@@ -673,6 +680,12 @@ int od_set_stream(od_handle h, void* s) {
   h->stream = (hipStream_t)s;
   return OD_OK;
 }
+int od_set_cooperative(od_handle h, int mode) {
+  if (!h || mode < 0 || mode > 2) return fail(OD_ERR_INVALID, "od_set_cooperative: mode 0 (automatic), 1 (never) or 2 (always)");
+  h->coop = mode;
+  return OD_OK;
+}
+
 int od_set_launch_config(od_handle h, int ppw, int waves_per_block) {
   if (!h || ppw < 0 || ppw > 64 || (ppw & (ppw - 1)) || !(waves_per_block == 0 || waves_per_block == 1 || waves_per_block == 4))
     return fail(OD_ERR_INVALID, "od_set_launch_config: ppw = 0 (auto) or a power of two <= 64; waves_per_block in {0, 1, 4}");

@@ -7,7 +7,7 @@
 
 namespace od {
 
-struct LaunchCfg { int ppw, wpb; };     // problems per wavefront (pow2 <= 64), wavefronts per workgroup (1 | 4)
+struct LaunchCfg { int ppw, wpb, coop; };     // problems per wavefront (pow2 <= 64), wavefronts per workgroup (1 | 4), cooperative kernel (od_coop.h)
 
 struct ModelVT {
   int id, kind;
@@ -16,6 +16,7 @@ struct ModelVT {
   double r_tol, kappa_eval, kappa_grad, eps_min, kappa_reg, gamma_reg, undercut;
   int max_iter, max_ls;
   double fric_default[4];
+  int has_coop;                                // the model has the cooperative (16 lanes per problem) state kernels
   int ngam, nbfr;                              // z indices of the impact / friction impulses
   std::array<int, 12> gam, bfr;
   hipError_t (*step_state)(const StepArgs<double>&, LaunchCfg, hipStream_t);        // pass 1, independent knots

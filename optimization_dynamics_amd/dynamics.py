@@ -104,6 +104,10 @@ class ImplicitDynamics:
         """launch tuning (0 / -1 = automatic), see od_set_launch_config"""
         self.lib.check(self.lib.cdll.od_set_launch_config(self._h, int(ppw), int(waves_per_block)))
 
+    def set_cooperative(self, mode=0):
+        """cooperative solve pass (16 lanes per problem): 0 automatic, 1 never, 2 always where the model has it"""
+        self.lib.check(self.lib.cdll.od_set_cooperative(self._h, int(mode)))
+
     def synchronize(self):
         self.lib.check(self.lib.cdll.od_synchronize(self._h))
 
