@@ -28,6 +28,60 @@ def _need(cond, msg):
         raise NotCoop(msg)
 
 
+def _dpp_block(ops, indent="    ", max_operands=28):
+    """C++ for a list of cross-lane operations, in two flavours: on the device ONE inline-asm block per chunk (a
+    single `s_nop 1` covers the DPP read-after-write hazard of all its instructions: they read registers written
+    before the block only), in the host test build the RowEmu calls.
+    ops: ("fmac" | "fnmac", lane, acc, src, mul)   acc (+)= src[lane] * (+-)mul
+         ("bc", lane, dst, src)                      dst = src[lane]"""
+    out = []
+    chunks, cur, cur_syms = [], [], set()
+    for op in ops:
+        syms = set(op[2:])
+        if cur and len(cur_syms | syms) > max_operands:
+            chunks.append(cur)
+            cur, cur_syms = [], set()
+        cur.append(op)
+        cur_syms |= syms
+    if cur:
+        chunks.append(cur)
+    out.append("#if defined(__HIP_DEVICE_COMPILE__)")
+    for ch in chunks:
+        outs, ins = [], []
+        for op in ch:
+            if op[0] == "bc":
+                if op[2] not in outs:
+                    outs.append(op[2])
+            elif op[2] not in outs:
+                outs.append(op[2])
+        for op in ch:
+            for e in (op[3:] if op[0] != "bc" else op[3:4]):
+                if e not in ins and e not in outs:
+                    ins.append(e)
+        num = {e: k for k, e in enumerate(outs + ins)}
+        lines = ["s_nop 1"]
+        for op in ch:
+            if op[0] == "bc":
+                lines.append("v_mov_b64_dpp %%%d, %%%d row_newbcast:%d row_mask:0xf bank_mask:0xf" % (num[op[2]], num[op[3]], op[1]))
+            else:
+                neg = "-" if op[0] == "fnmac" else ""
+                lines.append("v_fmac_f64_dpp %%%d, %%%d, %s%%%d row_newbcast:%d row_mask:0xf bank_mask:0xf"
+                             % (num[op[2]], num[op[3]], neg, num[op[4]], op[1]))
+        is_bc = {op[2] for op in ch if op[0] == "bc"}
+        cons_out = ", ".join(('"=&v"(%s)' if e in is_bc else '"+v"(%s)') % e for e in outs)
+        cons_in = ", ".join('"v"(%s)' % e for e in ins)
+        out.append(indent + 'asm("' + '\\n\\t"\n%s    "'.join([lines[0]] + lines[1:]) .replace("%s", indent) + '"')
+        out.append(indent + "    : %s : %s);" % (cons_out, cons_in))
+    out.append("#else")
+    for op in ops:
+        if op[0] == "bc":
+            out.append(indent + "%s = RO::template bc<%d>(%s);" % (op[2], op[1], op[3]))
+        else:
+            out.append(indent + "RO::template %s<%d>(%s, %s, %s);" % (op[0], op[1], op[2], op[3], op[4]))
+    out.append("#endif")
+    return "\n".join(out) + "\n"
+
+
 def emit_coop(m: ModelSpec, d: Derived) -> Optional[str]:
     try:
         return _emit(m, d)
@@ -231,9 +285,11 @@ def _emit(m: ModelSpec, d: Derived) -> str:
 
     def gather(name, fv, clamp):
         w("  template <class RO, class V> OD_HD static void %s(const V& P0, const V& P1, const V& D0, const V& D1, double* zr) {\n" % name)
+        ops = []
         for k in fv:
             lane, fld = lane_of_z(k)
-            w("    zr[%d] = RO::template bc<%d>(%s);\n" % (k, lane, fld))
+            ops.append(("bc", lane, "zr[%d]" % k, fld))
+        w(_dpp_block(ops))
         w("  }\n")
 
     w("  // replicated copies of the contact forces the dynamics rows (gather_r) / their Jacobian (gather_rz) read\n")
@@ -271,23 +327,27 @@ def _emit(m: ModelSpec, d: Derived) -> str:
     w("  }\n")
     w("  // Schur complement of the dynamics rows: d gamma_i = ty_i + t_i . dq,  d b_c = Wy_c - W_c . dq\n")
     w("  template <class RO, class F> OD_HD static void schur(const F& f, const typename RO::V* W, double* dqq) {\n")
+    ops = []
     for i in range(NC):
         for k in PN[i]:
             for j in PJ[i]:
-                w("    RO::template fmac<%d>(dqq[%d], f.t[%d], f.nv[%d][%d]);\n" % (i, k + nq * j, j, i, k))
+                ops.append(("fmac", i, "dqq[%d]" % (k + nq * j), "f.t[%d]" % j, "f.nv[%d][%d]" % (i, k)))
     for c in range(NK):
         wj = sorted(set(PJV[c]) | (set(PJ[partner[c]]) if partner[c] >= 0 else set()))
         for k in PNB[c]:
             for j in wj:
-                w("    RO::template fnmac<%d>(dqq[%d], W[%d], f.nbv[%d][%d]);\n" % (NC + c, k + nq * j, j, c, k))
+                ops.append(("fnmac", NC + c, "dqq[%d]" % (k + nq * j), "W[%d]" % j, "f.nbv[%d][%d]" % (c, k)))
+    w(_dpp_block(ops))
     w("  }\n")
     w("  template <class RO, class F> OD_HD static void rhs_update(const F& f, const typename RO::V& ty, const typename RO::V& Wy, double* rd) {\n")
+    ops = []
     for i in range(NC):
         for k in PN[i]:
-            w("    RO::template fnmac<%d>(rd[%d], ty, f.nv[%d][%d]);\n" % (i, k, i, k))
+            ops.append(("fnmac", i, "rd[%d]" % k, "ty", "f.nv[%d][%d]" % (i, k)))
     for c in range(NK):
         for k in PNB[c]:
-            w("    RO::template fnmac<%d>(rd[%d], Wy, f.nbv[%d][%d]);\n" % (NC + c, k, c, k))
+            ops.append(("fnmac", NC + c, "rd[%d]" % k, "Wy", "f.nbv[%d][%d]" % (c, k)))
+    w(_dpp_block(ops))
     w("  }\n")
     w("  // psi rows: psi_c + g[c] * gamma_partner + gc[c] (theta only)\n")
     w("  template <class T> OD_HD static void eval_gcoef(const T* th, T* g, T* gc) {\n")

@@ -561,22 +561,62 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
         rows_used = sorted({f for e in outs for f in e.free_symbols if f in row_idx}, key=lambda t: row_idx[t])
         for ps in rows_used:
             o.write("    const T %s = pre[%d];\n" % (ps.name, row_idx[ps]))
-        for sy, e in repl:
-            if sy not in need:
-                continue
+        done = set()
+
+        def emit_temp(sy, e):
             if sy in stored:
                 o.write("    const T %s = pre[%d];\n" % (sy.name, pre_idx[sy]))
             elif is_trig[sy] and not produce_trig:
                 o.write("    const T %s = tr[%d];\n" % (sy.name, tr_idx[sy]))
+            elif is_trig[sy] and sy in trig_slot:
+                k, fn = trig_slot[sy]
+                o.write("    const T %s = %s[%d];\n" % (sy.name, "ts_" if fn == "sin" else "tc_", k))
+                o.write("    tr[%d] = %s;\n" % (tr_idx[sy], sy.name))
             else:
                 o.write("    const T %s = %s;\n" % (sy.name, pr.doprint(e)))
                 if is_trig[sy]:
                     o.write("    tr[%d] = %s;\n" % (tr_idx[sy], sy.name))
+            done.add(sy)
+
+        trig_slot = {}
+        if produce_trig:
+            # the sines / cosines of z-dependent angles, evaluated together through the policy TP: the cooperative
+            # solver computes two angles side by side in the two halves of a lane row (od_coop.h::TrigHalves)
+            targs = []
+            for sy, e in repl:
+                if sy in need and is_trig[sy] and sy not in stored:
+                    a_ = e.args[0]
+                    if a_ not in targs:
+                        targs.append(a_)
+                    trig_slot[sy] = (targs.index(a_), "sin" if isinstance(e, sp.sin) else "cos")
+            if len(targs) >= 2:
+                first = set()
+                stack = [f for a_ in targs for f in a_.free_symbols if f in tdef]
+                while stack:
+                    t = stack.pop()
+                    if t in first:
+                        continue
+                    first.add(t)
+                    assert not is_trig[t], "an angle that depends on another sine / cosine"
+                    if t not in stored:
+                        stack += [f for f in tdef[t].free_symbols if f in tdef]
+                for sy, e in repl:
+                    if sy in first:
+                        emit_temp(sy, e)
+                o.write("    T ts_[%d], tc_[%d];\n" % (len(targs), len(targs)))
+                o.write("    { const T ta_[%d] = {%s}; TP::template sincos_n<%d>(ta_, ts_, tc_); }\n"
+                        % (len(targs), ", ".join(pr.doprint(a_) for a_ in targs), len(targs)))
+            else:
+                trig_slot = {}
+        for sy, e in repl:
+            if sy not in need or sy in done:
+                continue
+            emit_temp(sy, e)
         for k, e in enumerate(outs):
             o.write("    %s[%d] = %s;\n" % (out_name, k, pr.doprint(e)))
 
     o.write("  // r(z; theta, kappa = 0); also produces the shared trigonometric values tr[] at z\n")
-    o.write("  template <class T> OD_HD static void eval_r(const T* z, const T* th, const T* pre, T* tr, T* r) {\n")
+    o.write("  template <class TP = TrigDirect, class T> OD_HD static void eval_r(const T* z, const T* th, const T* pre, T* tr, T* r) {\n")
     body(need_r, red_r, "r", True)
     o.write("  }\n\n")
     o.write("  // structural nonzeros of rz at z (orthant variables possibly clamped); tr[] from eval_r at the same point\n")

@@ -70,6 +70,7 @@ struct RowEmu {
   static V sel(const B& m, const V& a, double b) { return sel(m, a, V(b)); }
   static V sel(const B& m, double a, double b) { return sel(m, V(a), V(b)); }
   template <int L> static double bc(const V& x) { return x.v[L]; }
+  template <int L0, int L1> static void bc2(const V& x, double& a, double& b) { a = x.v[L0]; b = x.v[L1]; }
   template <int L> static void fmac(double& acc, const V& x, double m) { acc = od_fma(x.v[L], m, acc); }
   template <int L> static void fnmac(double& acc, const V& x, double m) { acc = od_fma(x.v[L], -m, acc); }
   template <int N> static V shr(const V& x) { V r = x; for (int i = N; i < 16; ++i) r.v[i] = x.v[i - N]; return r; }
@@ -102,6 +103,10 @@ struct RowDev {
     double r;
     asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(L));
     return r;
+  }
+  template <int L0, int L1> __device__ __forceinline__ static void bc2(double x, double& a, double& b) {   // one nop for both
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\tv_mov_b64_dpp %1, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+        : "=&v"(a), "=&v"(b) : "v"(x), "n"(L0), "n"(L1));
   }
   template <int L> __device__ __forceinline__ static void fmac(double& acc, double x, double m) {
     asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(m), "n"(L));
@@ -194,6 +199,26 @@ template <class CM, class RO> struct CoopFact {
   int piv[NQ];
 };
 
+// Sines and cosines of the replicated residual (gen/<model>.h::eval_r<TP>): angles 2p and 2p+1 are evaluated side by
+// side, lanes 0..7 take the even one, their mirrors the odd one, and both results are broadcast back (a sin/cos pair
+// is ~45 instructions, the exchange 5).
+inline Vec16 od_sin(const Vec16& a) { Vec16 r; for (int i = 0; i < 16; ++i) r.v[i] = od_sin(a.v[i]); return r; }
+inline Vec16 od_cos(const Vec16& a) { Vec16 r; for (int i = 0; i < 16; ++i) r.v[i] = od_cos(a.v[i]); return r; }
+template <class RO> struct TrigHalves {
+  template <int N> OD_HD static void sincos_n(const double* a, double* s, double* c) {
+    using V = typename RO::V;
+    const typename RO::B half = RO::lane_flag(0xFF00u);
+#pragma unroll
+    for (int p = 0; p + 1 < N; p += 2) {
+      const V x = RO::sel(half, a[p + 1], a[p]);
+      const V sx = od_sin(x), cx = od_cos(x);
+      RO::template bc2<0, 8>(sx, s[p], s[p + 1]);
+      RO::template bc2<0, 8>(cx, c[p], c[p + 1]);
+    }
+    if constexpr (N & 1) { s[N - 1] = od_sin(a[N - 1]); c[N - 1] = od_cos(a[N - 1]); }
+  }
+};
+
 // sum / max over the 8 lanes of each half row; every lane of the half ends with the same bits
 template <class RO> OD_HD typename RO::V half_sum(typename RO::V v) {
   v = v + RO::xor1(v);
@@ -231,7 +256,7 @@ OD_HD void coop_eval_r(const CoopLanes<CM, RO>& L, const CoopVec<CM::NQ, typenam
 #pragma unroll
   for (int k = 0; k < CM::NQ; ++k) zr[CM::ZQ[k]] = z.q[k];
   CM::template gather_r<RO>(z.P0, z.P1, z.D0, z.D1, zr);
-  M::eval_r(zr, th, pre, tr, rr);
+  M::template eval_r<TrigHalves<RO>>(zr, th, pre, tr, rr);
 #pragma unroll
   for (int k = 0; k < CM::NQ; ++k) r.rd[k] = rr[CM::RDYN[k]];
   const V e1 = CM::template pick_e1<RO>(L, rr);
@@ -263,7 +288,8 @@ OD_HD void coop_viol(const CoopLanes<CM, RO>& L, const CoopRes<CM::NQ, typename 
   v = RO::sel(s != s, inf, v);              // hardware max drops NaNs: carry them as +inf through the reduction
   v = RO::sel(L.is_role, v, 0.0);
   v = half_max<RO>(v);
-  double de = RO::template bc<0>(v), dk = RO::template bc<8>(v);
+  double de, dk;
+  RO::template bc2<0, 8>(v, de, dk);
   const double nan = __builtin_nan("");
   de = od_fmax(de, ve);
   r_vio = (se != se || de == inf) ? nan : de;
@@ -444,7 +470,9 @@ OD_HD double coop_step_length(const CoopLanes<CM, RO>& L, const CoopVec<CM::NQ, 
   }
   a = od_min(a, V(1.0));
   a = half_min<RO>(a);
-  return od_min(RO::template bc<0>(a), RO::template bc<8>(a));
+  double a0, a1;
+  RO::template bc2<0, 8>(a, a0, a1);
+  return od_min(a0, a1);
 }
 
 // CVXOPT sec. 5.1.3: mu = <primal, dual>/ncones ; sigma = clamp(mu_aff/mu, 0, 1)^3  (od_solver.h::centering_kappa)
@@ -457,7 +485,8 @@ OD_HD double coop_centering(const CoopLanes<CM, RO>& L, const CoopVec<CM::NQ, ty
   V v = RO::sel(L.half, pa, p);            // lanes 0..7 sum <z1, z2>, the mirrors the affine products
   v = RO::sel(L.is_role, v, 0.0);
   v = half_sum<RO>(v);
-  const double s = RO::template bc<0>(v), sa = RO::template bc<8>(v);
+  double s, sa;
+  RO::template bc2<0, 8>(v, s, sa);
   const double mu = s * (1.0 / n);
   double q = sa * od_rcp(s);
   q = od_max(q, 0.0);

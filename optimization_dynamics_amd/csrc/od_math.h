@@ -63,6 +63,16 @@ OD_HD void od_sincos(double x, double& sn, double& cs) {
 }
 OD_HD double od_sin(double x) { double s, c; od_sincos(x, s, c); return s; }
 OD_HD double od_cos(double x) { double s, c; od_sincos(x, s, c); return c; }
+OD_HD float od_sin(float x);
+OD_HD float od_cos(float x);
+// how the generated residuals evaluate the sines and cosines of their N z-dependent angles: one after the other here;
+// the cooperative solver substitutes a policy that computes two angles side by side (od_coop.h::TrigHalves)
+struct TrigDirect {
+  template <int N, class T> OD_HD static void sincos_n(const T* a, T* s, T* c) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) { s[i] = od_sin(a[i]); c[i] = od_cos(a[i]); }
+  }
+};
 OD_HD double od_sqrt(double x) { return sqrt(x); }
 OD_HD double od_abs(double x) { return fabs(x); }
 OD_HD double od_pow(double x, double y) { return pow(x, y); }
