@@ -378,9 +378,9 @@ int ppw_of(const od_handle_s* h, long n) { return h->ppw > 0 ? h->ppw : od_auto_
 // pass-1 launch shape: 4 wavefronts per workgroup (one per SIMD) while that still spreads the batch over
 // the chip, problems per wavefront from od_auto_ppw (aims at one resident wavefront per SIMD)
 // The cooperative kernels put one problem on 16 lanes (4 per wavefront): they shorten the critical path of a problem
-// and pay off while the batch leaves lanes idle -- up to OD_COOP_AUTO_MAX problems (one 4-problem wavefront per SIMD);
+// and pay off while the batch leaves lanes idle -- up to OD_COOP_AUTO_MAX problems (measured: 8192 rollouts 5.4 ms against 5.7, 16384 10.4 against 6.6);
 // larger batches fill the lanes with whole problems instead.
-constexpr long OD_COOP_AUTO_MAX = 4096;
+constexpr long OD_COOP_AUTO_MAX = 8192;
 LaunchCfg cfg_of(const od_handle_s* h, long n) {
   LaunchCfg c;
   c.ppw = ppw_of(h, n);

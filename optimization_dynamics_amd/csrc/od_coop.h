@@ -58,6 +58,7 @@ inline Vec16 od_abs(const Vec16& a) { Vec16 r; for (int i = 0; i < 16; ++i) r.v[
 inline Vec16 od_max(const Vec16& a, const Vec16& b) { Vec16 r; for (int i = 0; i < 16; ++i) r.v[i] = od_max(a.v[i], b.v[i]); return r; }
 inline Vec16 od_min(const Vec16& a, const Vec16& b) { Vec16 r; for (int i = 0; i < 16; ++i) r.v[i] = od_min(a.v[i], b.v[i]); return r; }
 inline Vec16 od_fmax(const Vec16& a, const Vec16& b) { Vec16 r; for (int i = 0; i < 16; ++i) r.v[i] = od_fmax(a.v[i], b.v[i]); return r; }
+inline Vec16 od_fmin(const Vec16& a, const Vec16& b) { Vec16 r; for (int i = 0; i < 16; ++i) r.v[i] = od_fmin(a.v[i], b.v[i]); return r; }
 
 struct RowEmu {
   using V = Vec16;
@@ -116,8 +117,10 @@ struct RowDev {
   }
   template <int CTRL> __device__ __forceinline__ static double dpp32(double x) {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    // bound_ctrl: lanes whose source is outside the row read 0 (row_shr; nobody uses those lanes' results) -- without
+    // it the destination is tied to an `old` value and the compiler copies the source first (two more moves)
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
   }
   template <int N> __device__ __forceinline__ static double shr(double x) { return dpp32<0x110 + N>(x); }   // lane l <- lane l-N
@@ -233,9 +236,9 @@ template <class RO> OD_HD typename RO::V half_max(typename RO::V v) {
   return v;
 }
 template <class RO> OD_HD typename RO::V half_min(typename RO::V v) {
-  v = od_min(v, RO::xor1(v));
-  v = od_min(v, RO::xor2(v));
-  v = od_min(v, RO::half_mirror(v));
+  v = od_fmin(v, RO::xor1(v));
+  v = od_fmin(v, RO::xor2(v));
+  v = od_fmin(v, RO::half_mirror(v));
   return v;
 }
 
@@ -308,7 +311,8 @@ OD_HD bool coop_eval_factor(const CoopLanes<CM, RO>& L, const CoopVec<CM::NQ, ty
   using V = typename RO::V;
   constexpr int NQ = CM::NQ;
   // orthant members clamped from below at reg (rz!(...; reg)); cone members are not
-  const V P0c = RO::sel(L.is_contact, od_max(z.P0, V(reg)), z.P0), D0c = RO::sel(L.is_contact, od_max(z.D0, V(reg)), z.D0);
+  const V regl = RO::sel(L.is_contact, reg, -__builtin_inf());
+  const V P0c = od_fmax(z.P0, regl), D0c = od_fmax(z.D0, regl);
   double zr[M::NZ], a[M::NNZ];
 #pragma unroll
   for (int i = 0; i < M::NZ; ++i) zr[i] = 0.0;
@@ -345,6 +349,11 @@ OD_HD bool coop_eval_factor(const CoopLanes<CM, RO>& L, const CoopVec<CM::NQ, ty
         }
       }
     }
+    // role swap (gen/<model>.h: sw = |psi| > |s_psi|): the first pivot row is the head row A (on s_psi) if sw, the tail
+    // row B (on b) otherwise.  The rows are exchanged physically and the second row is reduced entry by entry, in the
+    // order of the lane-per-problem elimination.  (Folding the exchange into scalar coefficients, W = cA qA + cB qB,
+    // saves selects but subtracts two large products when the second pivot is small; a build with that form and with
+    // multiplicative role masks stopped converging on the device -- not bisected further, this is the stable form.)
     f.sw = od_abs(z.P0) > od_abs(z.D0);
     const V p1 = RO::sel(f.sw, z.P0, z.D0), o2 = RO::sel(f.sw, z.P1, z.D1), p2 = RO::sel(f.sw, z.D0, z.P0);
     f.o1 = RO::sel(f.sw, z.D1, z.P1);
@@ -421,15 +430,15 @@ OD_HD void coop_solve(const CoopLanes<CM, RO>& L, const CoopFact<CM, RO>& f, con
     if constexpr (CM::SH > 0) dgp = RO::template shr<CM::SH>(dg);
     const V dpsi = r.r2 - L.gcoef * dgp;
     x.P0 = RO::sel(L.is_cone, dpsi, dg);
+    // b, s_b exist on cone lanes only; contact lanes keep exact zeros (a select, not a multiplication by 0: the cone
+    // arithmetic of a contact lane may overflow when gamma or s underflow, and 0 * inf would poison its rows)
     x.P1 = RO::sel(L.is_cone, db, 0.0);
     x.D0 = RO::sel(L.is_cone, dsp, a1);
     x.D1 = RO::sel(L.is_cone, -a1, 0.0);
   } else {
     x.P0 = dg; x.P1 = V(0.0); x.D0 = a1; x.D1 = V(0.0);
   }
-  // lanes without a role stay put
-  x.P0 = RO::sel(L.is_role, x.P0, 0.0);
-  x.D0 = RO::sel(L.is_role, x.D0, 0.0);
+  // (lanes without a role compute along with finite garbage; every reduction masks them and no lane reads them)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -442,14 +451,14 @@ template <class RO> OD_HD typename RO::V coop_soc_step2(typename RO::V l0, typen
   V ll = l0 * l0, ld = l0 * d0;
   ll = ll - l1 * l1;
   ld = ld - l1 * d1;
-  ll = od_max(ll, V(1e-25)) + eps;
+  ll = od_fmax(ll, V(1e-25)) + eps;
   ld = ld + eps;
   const V isq = od_rsqrt(ll), ill = isq * isq;
   const V rs = ld * ill;
   const V c = (ld * isq + d0) * od_rcp(l0 * isq + 1.0);
   const V nv = od_abs(d1 * isq - c * l1 * ill);
   const V den = nv - rs;
-  return RO::sel(den > 0.0, od_min(V(1.0), tau * od_rcp(den)), 1.0);
+  return RO::sel(den > 0.0, tau * od_rcp(den), 1.0);      // the caller caps at 1
 }
 
 template <class CM, class RO>
@@ -468,11 +477,11 @@ OD_HD double coop_step_length(const CoopLanes<CM, RO>& L, const CoopVec<CM::NQ, 
     const V d0 = -RO::sel(L.half, d.D0, d.P0), d1 = -RO::sel(L.half, d.D1, d.P1);
     a = RO::sel(L.is_cone, coop_soc_step2<RO>(l0, l1, d0, d1, tau_soc), a);
   }
-  a = od_min(a, V(1.0));
+  a = od_fmin(a, V(1.0));
   a = half_min<RO>(a);
   double a0, a1;
   RO::template bc2<0, 8>(a, a0, a1);
-  return od_min(a0, a1);
+  return od_fmin(a0, a1);
 }
 
 // CVXOPT sec. 5.1.3: mu = <primal, dual>/ncones ; sigma = clamp(mu_aff/mu, 0, 1)^3  (od_solver.h::centering_kappa)
@@ -489,8 +498,8 @@ OD_HD double coop_centering(const CoopLanes<CM, RO>& L, const CoopVec<CM::NQ, ty
   RO::template bc2<0, 8>(v, s, sa);
   const double mu = s * (1.0 / n);
   double q = sa * od_rcp(s);
-  q = od_max(q, 0.0);
-  q = od_min(q, 1.0);
+  q = od_fmax(q, 0.0);
+  q = od_fmin(q, 1.0);
   return q * q * q * mu;
 }
 
@@ -515,15 +524,15 @@ OD_HD void coop_iteration(const CoopLanes<CM, RO>& L, const Opts<double>& o, con
   if constexpr (CONES) {
     const double aaff = coop_step_length<CM, RO>(L, z, D, 1.0, 1.0);
     double kap = coop_centering<CM, RO>(L, z, D, aaff);
-    kap = od_max(kap, o.kappa_eval * o.undercut_inv);
+    kap = od_fmax(kap, o.kappa_eval * o.undercut_inv);
     // r(z; kappa) from r(z; 0) on the head rows, then the second-order correction of the predictor
     r.rA = r.rA - kap + (D.P0 * D.D0 + D.P1 * D.D1);
     r.rB = r.rB + (D.P0 * D.D1 + D.P1 * D.D0);
     coop_solve<CM, PIV, RO>(L, f, z, r, D);
   }
-  const double vio = od_max(r_vio, k_vio);
-  const double tau = 1.0 - od_min(o.eps_min, vio * vio);
-  double alpha = coop_step_length<CM, RO>(L, z, D, tau, od_min(tau, 0.99));
+  const double vio = od_fmax(r_vio, k_vio);
+  const double tau = 1.0 - od_fmin(o.eps_min, vio * vio);
+  double alpha = coop_step_length<CM, RO>(L, z, D, tau, od_fmin(tau, 0.99));
   // backtracking until either violation does not increase (od_solver.h::line_search, sequential form)
   Vec zc;
   Res rc;

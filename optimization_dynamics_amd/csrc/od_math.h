@@ -143,6 +143,8 @@ template <class T> OD_HD T od_max(T a, T b) { return a > b ? a : b; }
 // IEEE maxNum (one instruction on the device; a NaN operand is dropped)
 OD_HD double od_fmax(double a, double b) { return __builtin_fmax(a, b); }
 OD_HD float od_fmax(float a, float b) { return __builtin_fmaxf(a, b); }
+OD_HD double od_fmin(double a, double b) { return __builtin_fmin(a, b); }
+OD_HD float od_fmin(float a, float b) { return __builtin_fminf(a, b); }
 
 // x^N by repeated squaring (N known at code-generation time)
 template <int N, class T> OD_HD T od_powi(T x) {
