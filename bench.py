@@ -2,18 +2,24 @@
 """Headline benchmark: contact-implicit steps + implicit gradients per second,
 hopper, T=100, batch=4096 rollouts per GPU (BASELINE.json metric).
 
-One "step" = one od_rollout launch: 4096 trajectories x 100 knots = 409 600 units, each unit =
-(q1,q2,u) -> (q3, dq3/dq1, dq3/dq2, dq3/du) honouring kappa_eval for the state and kappa_grad for
-the gradient (the reference's f + fx + fu, src/dynamics.jl:81-128).  Inputs are resident in HBM
-before the timed region.  Multi-GPU: one process per GPU (torchrun), trajectories sharded, no
-data-path collective (weak scaling: 4096 rollouts per GPU); --gather adds the all-gather of the
-linearisation (x+, A, B) that an outer iLQR backward pass would consume.
+One "step" = one od_rollout_compact call (two launches: the time recursion, then all gradients):
+4096 trajectories x 100 knots = 409 600 units, each unit = (q1,q2,u) -> (q3, dq3/dq1, dq3/dq2, dq3/du)
+honouring kappa_eval for the state and kappa_grad for the gradient (the reference's f + fx + fu,
+src/dynamics.jl:81-128; fx / fu are these blocks plus constants).  Inputs are resident in HBM
+before the timed region.  Multi-GPU: one process per GPU, trajectories sharded, no data-path
+collective (weak scaling: 4096 rollouts per GPU) -- every trajectory's Riccati pass is rank-local.
+`--gather` adds the one exchange the path can have, the all-gather of the linearisation for an outer
+loop that runs elsewhere, in compact form (x+ and dq3/d(q1,q2,u): 2.4x fewer bytes than x+, A, B).
 
-Prints ONE JSON line on rank 0.
+Launch: under `python -m torch.distributed.run ... bench.py --gpus N` (RANK / WORLD_SIZE in the
+environment) this process is one rank; `python bench.py --gpus N` on its own re-executes itself under
+torch.distributed.run with N ranks on 127.0.0.1.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -37,6 +43,34 @@ def algorithmic_flops_per_unit(iters_eval, stats):
     per_iter = F_rz + (2.0 / 3.0) * nz ** 3 + 4.0 * nz ** 2 + 2.0 * F_r + c_cone
     grad = F_rz + F_rth + (2.0 / 3.0) * nz ** 3 + 2.0 * nz ** 2 * nth
     return iters_eval * per_iter + grad, per_iter, grad
+
+
+def kernel_source_hash():
+    """hash of the device sources: profiles/*_traffic.json records it, a PMC measurement of other code is stale"""
+    d = os.path.join(ROOT, "optimization_dynamics_amd", "csrc")
+    hsh = hashlib.sha1()
+    for sub in ("", "gen"):
+        dd = os.path.join(d, sub)
+        for fn in sorted(os.listdir(dd)):
+            if fn.endswith((".h", ".hip", ".inc")):
+                hsh.update(fn.encode())
+                hsh.update(open(os.path.join(dd, fn), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+def measured_traffic(batch, horizon, gather):
+    """HBM bytes per od_rollout from the newest profiles/*_traffic.json (tools/summarize_profile.py after
+    tools/profile_round.sh: separate rocprofv3 --pmc passes, 2*FETCH_SIZE + WRITE_SIZE over both kernels)"""
+    if gather or batch != 4096 or horizon != 100:
+        return None, "PMC traffic is recorded for the default workload only"
+    pd = os.path.join(ROOT, "profiles")
+    cands = sorted(f for f in os.listdir(pd) if f.endswith("_traffic.json"))
+    if not cands:
+        return None, "no profiles/*_traffic.json"
+    rec = json.load(open(os.path.join(pd, cands[-1])))
+    if rec.get("source_hash") != kernel_source_hash():
+        return None, "profiles/%s is stale: kernels changed since that PMC run (re-run tools/profile_round.sh)" % cands[-1]
+    return float(rec["hbm_bytes_per_step"]), "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (2*FETCH + WRITE, both kernels)" % cands[-1]
 
 
 def algorithmic_bytes_per_unit():
@@ -131,71 +165,104 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="rollouts per GPU")
     ap.add_argument("--horizon", type=int, default=100)
-    ap.add_argument("--gather", action="store_true", help="all-gather (x+, A, B) after every step (RCCL)")
+    ap.add_argument("--gather", action="store_true", help="all-gather the compact linearisation (x+, dq3) after every step (RCCL)")
+    ap.add_argument("--dense", action="store_true", help="write the dense fx / fu matrices (od_rollout) instead of the compact dq3 (od_rollout_compact)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ppw", type=int, default=0, help="problems per wavefront (0 = library default)")
     ap.add_argument("--wpb", type=int, default=0, help="wavefronts per workgroup of the solve pass: 1 or 4 (0 = library default)")
+    ap.add_argument("--coop", type=int, default=0, help="cooperative solve pass: 0 automatic, 1 never, 2 always")
+    ap.add_argument("--test-emu-lib", default=None,
+                    help="TEST HARNESS ONLY (tests/test_distributed.py): run the ranks on CPU over gloo against the host-emulation build")
     args = ap.parse_args()
 
+    if "RANK" not in os.environ and args.gpus > 1:
+        # stand-alone launch: become N ranks (one per GPU) under torch.distributed.run on this node
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus = %d" % (args.gpus, world, world), file=sys.stderr)
+    emu = args.test_emu_lib is not None
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU path in the product library)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group(backend="gloo" if emu else "nccl")
+    if emu:
+        dev = torch.device("cpu")
+        sync = lambda: None
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU path in the product library)")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync = lambda: torch.cuda.synchronize(dev)
 
     from optimization_dynamics_amd import ImplicitDynamics, hopper
-    im = ImplicitDynamics(hopper, 0.05, r_tol=1e-8, kappa_eval_tol=1e-4, kappa_grad_tol=1e-3, device=dev)  # examples/hopper.jl:42
+    lib = None
+    if emu:
+        from optimization_dynamics_amd import _lib
+        lib = _lib.Library(args.test_emu_lib)
+    im = ImplicitDynamics(hopper, 0.05, r_tol=1e-8, kappa_eval_tol=1e-4, kappa_grad_tol=1e-3, device=dev, lib=lib)  # examples/hopper.jl:42
     if args.ppw or args.wpb:
         im.set_launch_config(args.ppw, args.wpb)
+    if args.coop:
+        im.set_cooperative(args.coop)
     B, T = args.batch, args.horizon
     x1, U = make_inputs(B, T, seed=rank)
     x1d = torch.tensor(x1, device=dev)
     Ud = torch.tensor(U, device=dev)
-    stream = torch.cuda.current_stream(dev)
+    stream = None if emu else torch.cuda.current_stream(dev)
 
     out = None
     gather_bufs = None
 
     def step():
         nonlocal out, gather_bufs
-        X, A, Bm, st, it, out = im.rollout(x1d, Ud, out=out)
+        # the unit's outputs exactly: x+ = [q2; q3] and dq3/d(q1, q2, u) (nq x (2nq+nu)) per knot -- od_rollout's dense
+        # A / B are the same numbers padded with the constant [0 I] and zero rows of fx / fu (--dense times those)
+        if args.dense:
+            X, A, Bm, st, it, out = im.rollout(x1d, Ud, out=out)
+            return st, it
+        X, G, st, it, out = im.rollout_compact(x1d, Ud, out=out)
         if args.gather and world > 1:
             if gather_bufs is None:
-                gather_bufs = [torch.empty(world * t.numel(), dtype=t.dtype, device=dev) for t in (out["X"], out["A"], out["Bm"])]
-            for buf, t in zip(gather_bufs, (out["X"], out["A"], out["Bm"])):
+                gather_bufs = [torch.empty(world * t.numel(), dtype=t.dtype, device=dev) for t in (out["X"], out["G"])]
+            for buf, t in zip(gather_bufs, (out["X"], out["G"])):
                 dist.all_gather_into_tensor(buf, t.reshape(-1))
         return st, it
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize(dev)
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize(dev)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sync()
+    ev = None if emu else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record(stream)      # the rollout kernel is launched on this (torch current) stream
+        if ev:
+            ev[k][0].record(stream)      # the rollout kernels are launched on this (torch current) stream
         st, it = step()
-        ev[k][1].record(stream)
-    torch.cuda.synchronize(dev)
+        if ev:
+            ev[k][1].record(stream)
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else elapsed / args.steps * 1e3
     units_per_rank = B * T
     value = world * units_per_rank * args.steps / elapsed
     stc = torch.bincount(st.flatten(), minlength=8).tolist()
@@ -203,7 +270,7 @@ def main():
     it_max = int(it.max().item())
 
     aux = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not emu:
         # auxiliary, NOT the headline: the same unit as independent knots (no time recursion), which is the
         # regime where the chip is full (reported so the roofline fraction can be read in both regimes)
         Bk = 262144
@@ -226,21 +293,23 @@ def main():
         F, per_iter, grad = algorithmic_flops_per_unit(it_eval, stats)
         ach_tflops = F * units_per_rank / (kernel_ms * 1e-3) / 1e12
         ach_gbs = algorithmic_bytes_per_unit() * units_per_rank / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_note = measured_traffic(B, T, args.gather or args.dense)
+        coop_on = bool(im.lib.cdll.od_uses_cooperative(im._h, B)) if hasattr(im.lib.cdll, "od_uses_cooperative") else False
         line = {
             "metric": "contact-implicit steps+grads/sec, hopper T=100 batch=4096",
             "value": value, "unit": "steps+grads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "hopper (RoboDojo path-following contact), T=%d, batch=%d rollouts per GPU, "
-                                   "h=0.05, kappa_eval=1e-4, kappa_grad=1e-3, r_tol=1e-8; od_rollout = f+fx+fu per knot" % (T, B),
-                       "units_per_step_per_gpu": units_per_rank, "parallelism": "rollouts sharded x%d, no collective%s" % (world, " + all-gather(x+,A,B)" if args.gather else "")},
-            "roofline": {"bound": "mfma", "bound_detail": "fp64 compute roof (FP64 vector = FP64 matrix peak on MI355X); no MFMA-shaped work on this path",
+                                   "h=0.05, kappa_eval=1e-4, kappa_grad=1e-3, r_tol=1e-8; od_rollout_compact = f+fx+fu per knot (q3, dq3/d(q1,q2,u))" % (T, B),
+                       "units_per_step_per_gpu": units_per_rank, "parallelism": "rollouts sharded x%d, no collective%s" % (world, " + all-gather(x+, dq3) compact" if args.gather else "")},
+            # the governing roof is the fp64 VECTOR-ALU rate (78.6 TFLOP/s, equal to the fp64 matrix peak on MI355X): the
+            # path is arithmetic on 4..20-wide systems with no GEMM-shaped work, nothing here runs on MFMA
+            "roofline": {"bound": "fp64-valu", "bound_detail": "fp64 vector ALU roof; algorithmic flops of the reference's dense-LU algorithm (SURVEY.md 8d) over the kernel time -- the device executes a sparse elimination, so this is a useful-work ratio",
                          "achieved": ach_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / FP64_PEAK_TFLOPS,
-                         # HBM bytes per od_rollout from the rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE over both
-                         # kernels, profiles/r1_pmc_summary.txt); only valid for the default workload
-                         "traffic": (469.4e6 if (B == 4096 and T == 100 and not args.gather) else None),
-                         "traffic_note": "bytes per launch pair, measured offline with rocprofv3 --pmc (profiles/); algorithmic = %d" % (algorithmic_bytes_per_unit() * units_per_rank),
-                         "kernel": "od_rollout = k_rollout_state<Model_hopper,double> (99 %) + k_grad_knots<Model_hopper,double>", "kernel_ms": kernel_ms,
+                         "traffic": traffic, "traffic_note": "%s; algorithmic = %d" % (traffic_note, algorithmic_bytes_per_unit() * units_per_rank),
+                         "kernel": ("k_rollout_state_coop<Coop_hopper> (one problem per 16 lanes)" if coop_on else "k_rollout_state<Model_hopper,double>")
+                                   + " (98 %) + k_grad_knots<Model_hopper,double>", "kernel_ms": kernel_ms,
                          "algorithmic_flops_per_unit": F, "mean_iterations_to_kappa_eval": it_eval, "max_iterations": it_max,
                          "hbm_algorithmic_GBps": ach_gbs, "hbm_frac": ach_gbs / HBM_PEAK_GBS},
             "solver_status_counts": {"converged(7)": stc[7], "other": int(sum(stc) - stc[7])},

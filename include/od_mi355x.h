@@ -87,6 +87,8 @@ int od_set_launch_config(od_handle h, int ppw, int waves_per_block);
  * critical path of small batches.  mode 0 = automatic (batches that leave lanes idle, models that have the kernels),
  * 1 = never, 2 = always where the model has them.  Results agree with the lane-per-problem kernels to rounding. */
 int od_set_cooperative(od_handle h, int mode);
+/* 1 if a solve pass over B problems would run the cooperative kernels under the handle's current settings */
+int od_uses_cooperative(od_handle h, long B);
 int od_synchronize(od_handle h);
 
 /* f (src/dynamics.jl:81-94) for B knots: d = [q2; q3].  x: 2nq, u: nu, d: 2nq per problem.
@@ -115,6 +117,11 @@ int od_step_grad_compact(od_handle h, long B, const void* x, const void* u, void
  * A: 2nq x 2nq per knot; Bm: 2nq x nu per knot.  A, Bm, status (T*B), iters (2*T*B) may be NULL. */
 int od_rollout(od_handle h, long B, int T, const void* x1, const void* U, void* X, void* A, void* Bm,
                int* status, int* iters);
+/* the same two launches with the linearisation in compact form: dq3 = d q3 / d(q1, q2, u1), nq x (2nq+nu) column-major
+ * per knot -- the only non-constant block of fx / fu (src/dynamics.jl:105-111,125): half the bytes of A and B, and what
+ * a multi-GPU gather of the linearisation should ship. */
+int od_rollout_compact(od_handle h, long B, int T, const void* x1, const void* U, void* X, void* dq3,
+                       int* status, int* iters);
 
 /* ---- next row of the scope table: the iLQR iteration around the path -----------------
  * Forward pass / Armijo line search of IterativeLQR (iLQR.solve!, examples/acrobot.jl:113): closed-loop

@@ -52,11 +52,13 @@ SIGNATURES = {
     "od_set_stream": (C.c_int, [_VP, _VP]),
     "od_set_launch_config": (C.c_int, [_VP, C.c_int, C.c_int]),
     "od_set_cooperative": (C.c_int, [_VP, C.c_int]),
+    "od_uses_cooperative": (C.c_int, [_VP, C.c_long]),
     "od_synchronize": (C.c_int, [_VP]),
     "od_step": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _IP, _IP]),
     "od_step_grad": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _VP, _VP, _IP, _IP]),
     "od_step_grad_compact": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _VP, _IP, _IP]),
     "od_rollout": (C.c_int, [_VP, C.c_long, C.c_int, _VP, _VP, _VP, _VP, _VP, _IP, _IP]),
+    "od_rollout_compact": (C.c_int, [_VP, C.c_long, C.c_int, _VP, _VP, _VP, _VP, _IP, _IP]),
     "od_rollout_policy": (C.c_int, [_VP, C.c_long, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _IP, _IP]),
     "od_ilqr_backward": (C.c_int, [_VP, C.c_long, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_double, _VP, _VP, _VP, _IP]),
     "od_bundle_workspace_bytes": (C.c_size_t, [_VP, C.c_long, C.c_int]),

@@ -425,12 +425,12 @@ StepArgs<double> step_args(od_handle_s* h, long B, long K, const void* x, const 
   a.dx = mkview<double>(dx, n * n, K, L);
   a.du = mkview<double>(du, n * nu, K, L);
   a.dq3 = mkview<double>(dq3, nq * (n + nu), K, L);
+  a.q3.p = nullptr; a.q3.se = 0; a.q3.sb = 0;
   a.status = mkview<int>(status, 1, K, L);
   a.iters = mkview<int>(iters, 2, K, L);
   a.zg.p = nullptr; a.zg.se = 0; a.zg.sb = 0;
   a.want_grad = want_grad;
   a.merge_grad_status = 0;
-  a.d_skip_q2 = 0;
   return a;
 }
 
@@ -452,12 +452,12 @@ int run_grad_pass(od_handle_s* h, StepArgs<double> g, long K, View<const double>
 }
 
 int run_step(od_handle_s* h, const char* fn, long B, const void* x, const void* u, void* d, void* dx, void* du,
-             void* dq3, int* status, int* iters, int want_grad, int d_skip_q2 = 0) {
+             void* dq3, int* status, int* iters, int want_grad, void* q3 = nullptr) {
   if (int rc = check_mech(h, fn)) return rc;
   if (B <= 0) return OD_OK;
   if (!x || (h->vt->nu > 0 && !u)) return fail(OD_ERR_INVALID, std::string(fn) + ": null input");
   StepArgs<double> a = step_args(h, B, B, x, u, d, dx, du, dq3, status, iters, want_grad);
-  a.d_skip_q2 = d_skip_q2;
+  a.q3 = mkview<double>(q3, h->vt->nq, B, h->layout);
   if (!want_grad) {
     OD_HIP(h->vt->step_state(a, cfg_of(h, B), h->stream));
     return OD_OK;
@@ -471,6 +471,7 @@ int run_step(od_handle_s* h, const char* fn, long B, const void* x, const void* 
     OD_HIP(h->vt->step_state(e, cfg_of(h, B), h->stream));
     StepArgs<double> g = a;
     g.d.p = nullptr;
+    g.q3.p = nullptr;
     g.merge_grad_status = 1;
     g.opts.kappa_eval = g.opts.kappa_grad;
     OD_HIP(h->vt->step_state(g, cfg_of(h, B), h->stream));
@@ -686,6 +687,8 @@ int od_set_cooperative(od_handle h, int mode) {
   return OD_OK;
 }
 
+int od_uses_cooperative(od_handle h, long B) { return (h && h->vt && cfg_of(h, B).coop) ? 1 : 0; }
+
 int od_set_launch_config(od_handle h, int ppw, int waves_per_block) {
   if (!h || ppw < 0 || ppw > 64 || (ppw & (ppw - 1)) || !(waves_per_block == 0 || waves_per_block == 1 || waves_per_block == 4))
     return fail(OD_ERR_INVALID, "od_set_launch_config: ppw = 0 (auto) or a power of two <= 64; waves_per_block in {0, 1, 4}");
@@ -710,25 +713,20 @@ int od_step_grad(od_handle h, long B, const void* x, const void* u, void* d, voi
 int od_step_grad_compact(od_handle h, long B, const void* x, const void* u, void* q3, void* dq3, int* status, int* iters) {
   if (int rc = check_mech(h, "od_step_grad_compact")) return rc;
   if (B <= 0) return OD_OK;
-  // q3 is the second half of d: shift the d view so that element nq+i of the virtual d lands on q3[i]
-  void* dshift = nullptr;
-  if (q3) {
-    View<double> v = mkview<double>(q3, h->vt->nq, B, h->layout);
-    dshift = v.p - (long)h->vt->nq * v.se;
-  }
-  return run_step(h, "od_step_grad_compact", B, x, u, dshift, nullptr, nullptr, dq3, status, iters, dq3 ? 1 : 0, 1);
+  return run_step(h, "od_step_grad_compact", B, x, u, nullptr, nullptr, nullptr, dq3, status, iters, dq3 ? 1 : 0, q3);
 }
 
-int od_rollout(od_handle h, long B, int T, const void* x1, const void* U, void* X, void* A, void* Bm, int* status, int* iters) {
-  if (int rc = check_mech(h, "od_rollout")) return rc;
+static int rollout_impl(od_handle h, const char* fn, long B, int T, const void* x1, const void* U, void* X, void* A, void* Bm, void* dq3,
+                        int* status, int* iters) {
+  if (int rc = check_mech(h, fn)) return rc;
   if (B <= 0 || T <= 0) return OD_OK;
-  if (!x1 || !U || !X) return fail(OD_ERR_INVALID, "od_rollout: null x1/U/X");
-  if (!fusable(h) && (A || Bm)) return fail(OD_ERR_UNSUPPORTED, "od_rollout: finite undercut with kappa_eval != kappa_grad");
+  if (!x1 || !U || !X) return fail(OD_ERR_INVALID, std::string(fn) + ": null x1/U/X");
+  const int want_grad = (A || Bm || dq3) ? 1 : 0;
+  if (!fusable(h) && want_grad) return fail(OD_ERR_UNSUPPORTED, std::string(fn) + ": finite undercut with kappa_eval != kappa_grad");
   const int n = 2 * h->vt->nq, nz = h->vt->nz;
   const long K = (long)T * B;
-  const int want_grad = (A || Bm) ? 1 : 0;
   RolloutArgs<double> r;
-  r.s = step_args(h, B, K, x1, U, nullptr, A, Bm, nullptr, status, iters, want_grad);
+  r.s = step_args(h, B, K, x1, U, nullptr, A, Bm, dq3, status, iters, want_grad);
   // X has (T+1)*B slots; knot k's d = [q2; q3] goes to slot k + B
   View<double> xv = mkview<double>(X, n, (long)(T + 1) * B, h->layout);
   r.x0 = xv;
@@ -744,6 +742,14 @@ int od_rollout(od_handle h, long B, int T, const void* x1, const void* U, void* 
   View<const double> xin;
   xin.p = xv.p; xin.se = xv.se; xin.sb = xv.sb;                        // state of knot k = slot k of X
   return run_grad_pass(h, r.s, K, xin);                                // pass 2: all T*B gradients
+}
+
+int od_rollout(od_handle h, long B, int T, const void* x1, const void* U, void* X, void* A, void* Bm, int* status, int* iters) {
+  return rollout_impl(h, "od_rollout", B, T, x1, U, X, A, Bm, nullptr, status, iters);
+}
+
+int od_rollout_compact(od_handle h, long B, int T, const void* x1, const void* U, void* X, void* dq3, int* status, int* iters) {
+  return rollout_impl(h, "od_rollout_compact", B, T, x1, U, X, nullptr, nullptr, dq3, status, iters);
 }
 
 int od_rollout_policy(od_handle h, long B, int T, int nalpha, const void* alphas, const void* x1, const void* xbar,

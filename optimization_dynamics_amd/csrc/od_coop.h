@@ -641,11 +641,13 @@ OD_HD void coop_knot_state(const CoopLanes<CM, RO>& L0, const StepArgs<double>& 
   if (RO::first_lane()) {
     if (a.d.ok()) {
       auto c = a.d.cursor(k);
-      if (a.d_skip_q2) c.skip(nq);
-      else {
 #pragma unroll
-        for (int i = 0; i < nq; ++i) c.put(xin[nq + i]);
-      }
+      for (int i = 0; i < nq; ++i) c.put(xin[nq + i]);
+#pragma unroll
+      for (int i = 0; i < nq; ++i) c.put(q3out[i]);
+    }
+    if (a.q3.ok()) {
+      auto c = a.q3.cursor(k);
 #pragma unroll
       for (int i = 0; i < nq; ++i) c.put(q3out[i]);
     }

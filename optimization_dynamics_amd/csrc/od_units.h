@@ -89,6 +89,7 @@ template <class T> struct StepArgs {
   View<const T> x;   // 2nq per problem: [q1; q2]
   View<const T> u;   // nu
   View<T> d;         // 2nq: [q2; q3]                                  (f)
+  View<T> q3;        // nq: q3 alone (compact output, alternative to d)
   View<T> dx;        // 2nq x 2nq col-major, ALL entries written        (fx)
   View<T> du;        // 2nq x nu  col-major, ALL entries written        (fu)
   View<T> dq3;       // compact nq x (2nq+nu) col-major = d q3/d(q1,q2,u) (alternative to dx/du)
@@ -97,7 +98,6 @@ template <class T> struct StepArgs {
   View<T> zg;        // workspace, nz+1 per problem: gradient iterate and clamp (pass 1 -> pass 2)
   int want_grad;
   int merge_grad_status;   // 1: this is the separate grad solve of a non-fusable step: merge into status / iters[1]
-  int d_skip_q2;     // 1: only rows nq..2nq of d are written (compact q3 output)
 };
 
 // pass-2 output: dq3/d(q1,q2,u) scattered into the reference's dx / du layout (and/or compact dq3)
@@ -144,11 +144,13 @@ OD_HD void knot_state(const StepArgs<T>& a, long k, const T* xin, const T* uin, 
   for (int i = 0; i < nq; ++i) q3out[i] = z[M::ZQ[i]];
   if (a.d.ok()) {
     auto c = a.d.cursor(k);
-    if (a.d_skip_q2) c.skip(nq);
-    else {
 #pragma unroll
-      for (int i = 0; i < nq; ++i) c.put(xin[nq + i]);
-    }
+    for (int i = 0; i < nq; ++i) c.put(xin[nq + i]);
+#pragma unroll
+    for (int i = 0; i < nq; ++i) c.put(q3out[i]);
+  }
+  if (a.q3.ok()) {
+    auto c = a.q3.cursor(k);
 #pragma unroll
     for (int i = 0; i < nq; ++i) c.put(q3out[i]);
   }

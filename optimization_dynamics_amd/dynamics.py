@@ -200,6 +200,20 @@ class ImplicitDynamics:
         Bm = out["Bm"].view(nu, n, T, B).transpose(0, 1) if grads else None
         return out["X"], A, Bm, out["st"], out["it"], out
 
+    def rollout_compact(self, x1, U, out=None):
+        """rollout with the linearisation in compact form: -> X (2nq, T+1, B), G (nq, 2nq+nu, T, B) = dq3/d(q1, q2, u1)
+        per knot (the non-constant block of fx / fu), status (T, B), iters (2, T, B), out"""
+        self._sync_friction(); self._use_current_stream()
+        x1, U = self._prep(x1), self._prep(U)
+        nu_, T, B = U.shape
+        nq, n, nu = self.model.nq, 2 * self.model.nq, self.model.nu
+        if out is None:
+            out = dict(X=self._new(n, T + 1, B), G=self._new(nq * (n + nu), T, B),
+                       st=self._new(T, B, dtype=torch.int32), it=self._new(2, T, B, dtype=torch.int32))
+        self.lib.check(self.lib.cdll.od_rollout_compact(self._h, B, T, _ptr(x1), _ptr(U), _ptr(out["X"]), _ptr(out["G"]),
+                                                        _ptr(out["st"]), _ptr(out["it"])))
+        return out["X"], out["G"].view(n + nu, nq, T, B).transpose(0, 1), out["st"], out["it"], out
+
     # -- scalar host path (reference signatures) ------------------------------------------------
     def _host(self, fn, x, u, out):
         self._sync_friction()

@@ -1,7 +1,9 @@
-"""Multi-GPU sharding of the independent units (rollouts / knots / bundle knots): one process per
-GPU (torchrun), no collective on the data path.  The only exchange the path has is the all-gather
-of the per-knot linearisation (x_{t+1}, A_t, B_t) that an outer iLQR backward pass consumes once per
-iteration; over RCCL this is one fused all_gather_into_tensor per array.
+"""Multi-GPU sharding of the independent units (rollouts / knots / bundle knots): one process per GPU, no collective
+on the data path -- every trajectory's backward (Riccati) pass is local to the rank that rolled it out.  The only
+exchange the path can have is an all-gather of the per-knot linearisation for an outer loop that runs elsewhere
+(SURVEY.md 8(e)); it ships the COMPACT form, x+ (2nq) and dq3/d(q1, q2, u) (nq x (2nq+nu)) per knot -- the dense A / B
+of the reference's callbacks are those numbers plus constant rows (src/dynamics.jl:105-111,125) and 2.4x the bytes --
+as one all_gather_into_tensor per array into a preallocated buffer, read through a view (no concatenation copy).
 The reference has no distributed code at all (single Julia process)."""
 import torch
 import torch.distributed as dist
@@ -14,18 +16,37 @@ def shard_range(n, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_linearization(X, A, Bm, group=None):
-    """All-gather per-rank rollout outputs along the batch (last) axis.
-    X: (2nq, T+1, B_local), A: (2nq, 2nq, T, B_local), Bm: (2nq, nu, T, B_local); every rank must hold
-    the same B_local (pad the last shard otherwise).  Returns the concatenated tensors."""
+def gather_batch(tensors, group=None, bufs=None):
+    """All-gather per-rank tensors (..., B_local) along the batch (last) axis; every rank must hold the same B_local
+    (pad the last shard otherwise).  Returns views (world, ..., B_local) of the gather buffers: slab r is rank r's
+    shard -- `.movedim(0, -2).reshape(..., world*B_local)` orders them like the unsharded batch when a flat batch axis
+    is needed.  `bufs` (returned as second value) can be passed back in to reuse the buffers."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return X, A, Bm
+        return [t.unsqueeze(0) for t in tensors], bufs
     world = dist.get_world_size(group)
-    outs = []
-    for t in (X, A, Bm):
-        t = t.contiguous()
-        buf = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(buf.view(-1), t.view(-1), group=group)
-        # (world, ..., B_local) -> (..., world*B_local)
-        outs.append(torch.cat(list(buf.unbind(0)), dim=-1))
-    return tuple(outs)
+    if bufs is None:
+        bufs = [torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device) for t in tensors]
+    for buf, t in zip(bufs, tensors):
+        dist.all_gather_into_tensor(buf.view(-1), t.contiguous().view(-1), group=group)
+    return bufs, bufs
+
+
+def gather_linearization(X, G, group=None):
+    """compact linearisation of sharded rollouts, concatenated along the batch axis: X (2nq, T+1, B), G (nq, 2nq+nu, T, B)"""
+    (Xg, Gg), _ = gather_batch([X, G], group)
+    return tuple(torch.cat(list(t.unbind(0)), dim=-1) for t in (Xg, Gg))
+
+
+def dense_linearization(X, G):
+    """fx / fu of the reference from the compact form: A (2nq, 2nq, T, B) = [[0 I]; [dq3/dq1 dq3/dq2]], Bm (2nq, nu, T, B)
+    = [0; dq3/du]  (src/dynamics.jl:105-111,125)"""
+    nq = G.shape[0]
+    n = 2 * nq
+    nu = G.shape[1] - n
+    T, B = G.shape[2], G.shape[3]
+    A = torch.zeros(n, n, T, B, dtype=G.dtype, device=G.device)
+    A[:nq, nq:] = torch.eye(nq, dtype=G.dtype, device=G.device)[:, :, None, None]
+    A[nq:, :] = G[:, :n]
+    Bm = torch.zeros(n, nu, T, B, dtype=G.dtype, device=G.device)
+    Bm[nq:] = G[:, n:]
+    return A, Bm

@@ -95,6 +95,17 @@ def check_layouts(lib, device, name, B):
     assert torch.equal(DXm.view(B, n, n).permute(2, 1, 0), DX)          # [b, col, row] -> (row, col, b)
     assert torch.equal(DUm.view(B, nu, n).permute(2, 1, 0), DU)
     assert torch.equal(stm, st)
+    # compact outputs in both layouts (od_step_grad_compact: q3 has its own nq-per-problem stride)
+    nq = n // 2
+    Q3, G, st2, it2 = im.step_grad_compact(torch.tensor(X), torch.tensor(U))
+    lib.check(lib.cdll.od_set_layout(im._h, _lib.LAYOUT_BATCH_MAJOR))
+    Q3m = torch.full((B + 2, nq), 7.0, dtype=torch.float64, device=im.device)          # two guard rows behind the buffer
+    Gm = torch.empty(B, nq * (n + nu), dtype=torch.float64, device=im.device)
+    lib.check(lib.cdll.od_step_grad_compact(im._h, B, Xm.data_ptr(), Um.data_ptr(), Q3m.data_ptr(), Gm.data_ptr(), stm.data_ptr(), 0))
+    im.synchronize()
+    lib.check(lib.cdll.od_set_layout(im._h, _lib.LAYOUT_BATCH_MINOR))
+    assert torch.equal(Q3m[:B].T, Q3) and (Q3m[B:] == 7.0).all()
+    assert torch.equal(Gm.view(B, n + nu, nq).permute(2, 1, 0), G)
 
 
 def check_rollout(oracle, lib, device, B, T, name="hopper", u_sigma=0.3):
@@ -420,3 +431,54 @@ def check_live_setters(lib, device):
     assert abs(info.project(u, grads=False)[0][2, 0].item() - 12.5) < 2e-3
     info.lib.check(info.lib.cdll.od_set_u_max(info._h, 5.0))
     assert abs(info.project(u, grads=False)[0][2, 0].item() - 5.0) < 2e-3
+
+
+# ---- cooperative (16 lanes per problem) state kernels against the lane-per-problem kernels ----------------------
+def check_coop_vs_serial(lib, device, name, B):
+    """same iteration counts and status on every knot; next configuration equal to rounding (the two kernels do the
+    same arithmetic in a different association order: 1e-12 typical, up to the solver's own r_tol on the few knots
+    whose solution is that ill determined); gradients come from the same (pivoted) second pass"""
+    X, U = W.knots(name, B, seed=31)
+    im = make_im(name, lib, device)
+    Xd, Ud = torch.tensor(X, device=device), torch.tensor(U, device=device)
+    im.set_cooperative(1)
+    ref = [t.cpu().numpy() for t in im.step_grad(Xd, Ud)]
+    im.set_cooperative(2)
+    got = [t.cpu().numpy() for t in im.step_grad(Xd, Ud)]
+    D1, st1, it1 = im.step(Xd, Ud)
+    # status and iterations to both tolerances: equal, except for a knot whose violation sits within rounding of a
+    # tolerance when the test is made (the two kernels associate their sums differently) -- at most one in a thousand
+    same = (ref[3] == got[3]) & (ref[4] == got[4]).all(0)
+    assert same.mean() >= 0.999, same.mean()
+    ok = ((ref[3] & 3) == 3) & ((got[3] & 3) == 3)
+    assert ok.mean() > 0.99
+    e_all = np.abs(ref[0] - got[0]).max(0)
+    e = e_all[ok & same]
+    assert np.median(e) < 1e-14 and np.quantile(e, 0.99) < 1e-11 and e.max() < 1e-7, (np.median(e), e.max())
+    assert e_all[ok].max() < STATE_TOL
+    assert np.array_equal(D1.cpu().numpy(), got[0])                                # od_step == od_step_grad state
+    g = W.grad_rel_err(np.concatenate([ref[1], ref[2]], 1), np.concatenate([got[1], got[2]], 1))[ok & same]
+    assert np.median(g) < 1e-12 and (g < GRAD_TOL).mean() > 0.998
+    return float(e.max())
+
+
+def check_coop_rollout(oracle, lib, device, B, T):
+    """cooperative rollout: == chained cooperative steps bitwise; against the oracle within the rollout tolerances"""
+    x1, U = W.hopper_rollout_inputs(B, T, seed=22, u_sigma=0.5)
+    im = make_im("hopper", lib, device)
+    im.set_cooperative(2)
+    X, A, Bm, st, it, _ = im.rollout(torch.tensor(x1, device=device), torch.tensor(U, device=device))
+    for t in (0, min(T - 1, 7)):
+        D, DX, DU, s1, i1 = im.step_grad(X[:, t], torch.tensor(U[:, t], device=device))
+        assert torch.equal(D, X[:, t + 1]) and torch.equal(s1, st[t]) and torch.equal(i1, it[:, t])
+    Xo, Ao, Bo, bad = oracle.rollout(make_sim(oracle, "hopper"), x1, U)
+    Xn = X.cpu().numpy()
+    ok = ((st.cpu().numpy() & 3) == 3).all(0)
+    assert ok.mean() > 0.9
+    err = np.abs(Xn - Xo)[:, :, ok].max(0)
+    scale = np.maximum(1e-2, np.abs(Xo)[:, :, ok].max(0))
+    assert (err / scale)[: min(T, 10) + 1].max() < STATE_TOL
+    assert np.median((err / scale)[-1]) < 1e-6
+    im.set_cooperative(1)
+    X1, _, _, st1, it1, _ = im.rollout(torch.tensor(x1, device=device), torch.tensor(U, device=device))
+    assert (it1 == it).double().mean().item() > 0.995       # a differing count needs a knot at the edge of a tolerance

@@ -1,0 +1,73 @@
+"""Cooperative solve pass (csrc/od_coop.h: one problem per 16-lane DPP row, contacts and cones in their own lanes).
+CPU tier: the row is emulated lane by lane (RowEmu, tests/host_emu) -- the same block algebra, routing tables and
+reductions as on the device, so the lane bookkeeping is covered without a GPU.  GPU tier: the DPP instructions."""
+import numpy as np
+import pytest
+import torch
+
+import parity_checks as P
+import workloads as W
+
+COOP_MODELS = ["hopper", "acrobot_impact"]
+
+
+def test_models_with_cooperative_kernels(emu_lib):
+    from optimization_dynamics_amd import models
+    im = P.make_im("cartpole_friction", emu_lib, "cpu")
+    im.set_cooperative(2)                     # no cooperative kernels for this model: silently the usual ones
+    X, U = W.knots("cartpole_friction", 32, seed=3)
+    a = im.step(torch.tensor(X), torch.tensor(U))[0]
+    im.set_cooperative(1)
+    assert torch.equal(a, im.step(torch.tensor(X), torch.tensor(U))[0])
+    assert emu_lib.cdll.od_set_cooperative(im._h, 3) == -1
+
+
+@pytest.mark.parametrize("name", COOP_MODELS)
+def test_coop_matches_lane_per_problem_emulated(emu_lib, name):
+    P.check_coop_vs_serial(emu_lib, "cpu", name, 1024)
+
+
+@pytest.mark.parametrize("name", COOP_MODELS)
+def test_coop_against_oracle_emulated(oracle, emu_lib, name):
+    im = P.make_im(name, emu_lib, "cpu")      # automatic mode picks the cooperative kernels for batches this small
+    P.check_step_grad(oracle, emu_lib, "cpu", name, 512)
+
+
+def test_coop_rollout_emulated(oracle, emu_lib):
+    P.check_coop_rollout(oracle, emu_lib, "cpu", 32, 30)
+
+
+def test_coop_finite_undercut_emulated(oracle, emu_lib):
+    """two separate passes (eval, grad) through the cooperative kernel: status / iteration merge"""
+    name = "hopper"
+    X, U = W.knots(name, 128, seed=61)
+    im = P.make_im(name, emu_lib, "cpu", options=dict(undercut=5.0))
+    im.set_cooperative(2)
+    a = [t.numpy() for t in im.step_grad(torch.tensor(X), torch.tensor(U))]
+    im.set_cooperative(1)
+    b = [t.numpy() for t in im.step_grad(torch.tensor(X), torch.tensor(U))]
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    assert np.abs(a[0] - b[0]).max() < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", COOP_MODELS)
+def test_coop_matches_lane_per_problem(gpu_lib, name):
+    P.check_coop_vs_serial(gpu_lib, "cuda:0", name, 8192)
+
+
+@pytest.mark.gpu
+def test_coop_rollout(oracle, gpu_lib):
+    P.check_coop_rollout(oracle, gpu_lib, "cuda:0", 96, 40)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 3, 5, 63, 257])
+def test_coop_ragged_batches(gpu_lib, B):
+    """rows of a wavefront / wavefronts of a workgroup without a problem"""
+    X, U = W.knots("hopper", B, seed=81)
+    im = P.make_im("hopper", gpu_lib, "cuda:0")
+    Xd, Ud = torch.tensor(X, device="cuda:0"), torch.tensor(U, device="cuda:0")
+    im.set_cooperative(2); a = im.step_grad(Xd, Ud)
+    im.set_cooperative(1); b = im.step_grad(Xd, Ud)
+    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]) and (a[0] - b[0]).abs().max().item() < 1e-8

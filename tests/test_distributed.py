@@ -1,5 +1,6 @@
 """N>1 path on CPU: two gloo ranks shard a batch of rollouts (no data-path collective), then
-all-gather the linearisation (x+, A, B) the way an outer iLQR backward pass would consume it.
+all-gather the compact linearisation (x+, dq3) the way an outer loop elsewhere would consume it; and
+bench.py's own multi-rank launch (`python bench.py --gpus 2`).
 Each rank drives the host-emulation build of the product library (CPU test tier)."""
 import os
 import socket
@@ -36,8 +37,9 @@ def _worker(rank, world, port, emu_path, outdir):
     x1, U = W.hopper_rollout_inputs(B, T, seed=3, u_sigma=0.3)
     lo, hi = parallel.shard_range(B, world, rank)
     im = P.make_im("hopper", lib, "cpu")
-    X, A, Bm, st, it, _ = im.rollout(torch.tensor(x1[:, lo:hi]), torch.tensor(U[:, :, lo:hi]))
-    Xg, Ag, Bg = parallel.gather_linearization(X.contiguous(), A.contiguous(), Bm.contiguous())
+    X, G, st, it, _ = im.rollout_compact(torch.tensor(x1[:, lo:hi]), torch.tensor(U[:, :, lo:hi]))
+    Xg, Gg = parallel.gather_linearization(X.contiguous(), G.contiguous())
+    Ag, Bg = parallel.dense_linearization(Xg, Gg)
     if rank == 0:
         np.savez(os.path.join(outdir, "gathered.npz"), X=Xg.numpy(), A=Ag.numpy(), B=Bg.numpy())
     dist.barrier()
@@ -70,3 +72,21 @@ def test_two_rank_sharded_rollout_and_allgather(emu_lib, tmp_path):
     assert np.array_equal(g["X"], X.numpy())
     assert np.array_equal(g["A"], A.numpy())
     assert np.array_equal(g["B"], Bm.numpy())
+
+
+def test_bench_gpus_flag_spawns_ranks(emu_lib):
+    """`python bench.py --gpus 2` without a launcher: two ranks appear and the line says n_gpus = 2 (host-emulation
+    library over gloo here; on a GPU box the same path runs one rank per GPU over RCCL)"""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16",
+           "--horizon", "6", "--gather", "--test-emu-lib", emu_lib.path]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
+    assert rec["config"]["units_per_step_per_gpu"] == 16 * 6
+    assert rec["value"] > 0 and "all-gather" in rec["config"]["parallelism"]

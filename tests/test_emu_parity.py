@@ -131,6 +131,7 @@ def test_ragged_batch_sizes_and_launch_configs(oracle, emu_lib, B):
     name = "acrobot_impact"
     X, U = W.knots(name, B, seed=81)
     im = P.make_im(name, emu_lib, "cpu")
+    im.set_cooperative(1)          # the lane-per-problem kernels: bitwise identical under every mapping (tests/test_coop.py has the other)
     ref = None
     for ppw, wpb in [(0, 0), (1, 1), (4, 4), (16, 4), (64, 1), (64, 4)]:
         im.set_launch_config(ppw, wpb)

@@ -37,6 +37,11 @@ out.append("k_rollout_state: %d wavefronts, %.2f M VALU instructions per wavefro
            % (s["SQ_WAVES"], s["SQ_INSTS_VALU"] / s["SQ_WAVES"] / 1e6, s["SQ_WAVE_CYCLES"] / s["SQ_INSTS_VALU"],
               100 * s["SQ_ACTIVE_INST_VALU"] / s["SQ_WAVE_CYCLES"], 100 * s["SQ_WAIT_ANY"] / s["SQ_WAVE_CYCLES"],
               100 * s["SQ_WAIT_INST_ANY"] / s["SQ_WAVE_CYCLES"]))
+sys.path.insert(0, ROOT)
+import bench
+json.dump({"tag": tag, "workload": "bench.py default (hopper T=100 batch=4096, od_rollout_compact)", "hbm_bytes_per_step": tot,
+           "formula": "2*FETCH_SIZE + WRITE_SIZE [KB*1024] over k_rollout_state* and k_grad_knots, mean per dispatch",
+           "source_hash": bench.kernel_source_hash()}, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
 notes = os.path.join(dst, tag + "_pmc_notes.txt")
 if os.path.exists(notes):
     out.append("")

@@ -14,7 +14,7 @@ lib = _lib.Library(libp) if libp else _lib.default_library()
 x1, U = W.hopper_rollout_inputs(B, T, seed=0)
 im = P.make_im("hopper", lib, "cuda:0")
 if len(sys.argv) > 5:
-    o = im.get_options(); o.max_iter = int(sys.argv[5]); im.set_options(o)
+    im.set_options(max_iter=int(sys.argv[5]))
 im.set_cooperative(mode)
 x1d, Ud = torch.tensor(x1, device="cuda:0"), torch.tensor(U, device="cuda:0")
 r = im.rollout(x1d, Ud); torch.cuda.synchronize()
