@@ -87,6 +87,11 @@ int od_set_launch_config(od_handle h, int ppw, int waves_per_block);
  * critical path of small batches.  mode 0 = automatic (batches that leave lanes idle, models that have the kernels),
  * 1 = never, 2 = always where the model has them.  Results agree with the lane-per-problem kernels to rounding. */
 int od_set_cooperative(od_handle h, int mode);
+/* diagnostics: the iterate at which the last od_step_grad* / od_rollout* call on this handle differentiated each of its
+ * K knots -- z at the first iterate satisfying (r_tol, kappa_grad) and, in row nz, the clamp of the orthant variables
+ * RoboDojo's differentiate_solution! uses -- as (nz+1) x K, batch-minor, into a device buffer (a copy of the hand-over
+ * workspace of the two-pass scheme).  Lets a checker recompute dz = -rz^{-1} rtheta at exactly that point. */
+int od_get_grad_iterates(od_handle h, long K, void* out);
 /* 1 if a solve pass over B problems would run the cooperative kernels under the handle's current settings */
 int od_uses_cooperative(od_handle h, long B);
 int od_synchronize(od_handle h);

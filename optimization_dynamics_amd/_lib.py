@@ -53,6 +53,7 @@ SIGNATURES = {
     "od_set_launch_config": (C.c_int, [_VP, C.c_int, C.c_int]),
     "od_set_cooperative": (C.c_int, [_VP, C.c_int]),
     "od_uses_cooperative": (C.c_int, [_VP, C.c_long]),
+    "od_get_grad_iterates": (C.c_int, [_VP, C.c_long, _VP]),
     "od_synchronize": (C.c_int, [_VP]),
     "od_step": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _IP, _IP]),
     "od_step_grad": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _VP, _VP, _IP, _IP]),

@@ -687,6 +687,14 @@ int od_set_cooperative(od_handle h, int mode) {
   return OD_OK;
 }
 
+int od_get_grad_iterates(od_handle h, long K, void* out) {
+  if (!h || !out || K <= 0) return fail(OD_ERR_INVALID, "od_get_grad_iterates: null handle / buffer");
+  const size_t n = (size_t)(h->vt->nz + 1) * (size_t)K;
+  if (!h->work || h->work_elems < n) return fail(OD_ERR_INVALID, "od_get_grad_iterates: no gradient pass over that many knots has run on this handle");
+  OD_HIP(hipMemcpyAsync(out, h->work, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  return OD_OK;
+}
+
 int od_uses_cooperative(od_handle h, long B) { return (h && h->vt && cfg_of(h, B).coop) ? 1 : 0; }
 
 int od_set_launch_config(od_handle h, int ppw, int waves_per_block) {

@@ -108,6 +108,15 @@ class ImplicitDynamics:
         """cooperative solve pass (16 lanes per problem): 0 automatic, 1 never, 2 always where the model has it"""
         self.lib.check(self.lib.cdll.od_set_cooperative(self._h, int(mode)))
 
+    def grad_iterates(self, K):
+        """(nz+1, K): the iterates (and, last row, orthant clamps) at which the last step_grad / rollout call on this
+        handle took its K implicit gradients -- diagnostics for the extended-precision arbiter (oracle/arbiter.c)"""
+        self._use_current_stream()
+        nz = self.lib.model_dims(self.model.name)["nz"]
+        out = self._new(nz + 1, K)
+        self.lib.check(self.lib.cdll.od_get_grad_iterates(self._h, K, _ptr(out)))
+        return out
+
     def synchronize(self):
         self.lib.check(self.lib.cdll.od_synchronize(self._h))
 

@@ -214,8 +214,8 @@ static void rz_reg(const od_oracle_model* m, double* rz, const double* z, const 
  * interior_point_solve! (RoboDojo src/solver/interior_point.jl, recalled).
  *   z in/out, theta in.  dz (nz x nth col-major) written when diff_sol.  returns status (1 ok).
  * -------------------------------------------------------------------------------------------- */
-int od_oracle_ip_solve(int model_id, const od_oracle_opts* o, double kappa_tol, int diff_sol,
-                       double* z, const double* th, double* dz, int* iters_out) {
+static int ip_solve_impl(int model_id, const od_oracle_opts* o, double kappa_tol, int diff_sol,
+                         double* z, const double* th, double* dz, int* iters_out, double* reg_out) {
   const od_oracle_model* m = od_oracle_models[model_id];
   const int nz = m->nz, nth = m->nth, ncone = m->nort + m->nsoc;
   double r[NZMAX], Da[NZMAX], D[NZMAX], zc[NZMAX], rz[NZMAX * NZMAX];
@@ -274,6 +274,7 @@ int od_oracle_ip_solve(int model_id, const od_oracle_opts* o, double kappa_tol, 
     /* differentiate_solution!: dz = -rz(z*)^{-1} rtheta(z*), reg = max(reg_val, kappa_tol*gamma_reg) */
     double reg = kappa_tol * o->gamma_reg;
     if (reg_val > reg) reg = reg_val;
+    if (reg_out) *reg_out = reg;
     rz_reg(m, rz, z, th, reg);
     m->rth(z, th, dz);
     lu_factor(nz, rz, piv);
@@ -283,6 +284,11 @@ int od_oracle_ip_solve(int model_id, const od_oracle_opts* o, double kappa_tol, 
     }
   }
   return status;
+}
+
+int od_oracle_ip_solve(int model_id, const od_oracle_opts* o, double kappa_tol, int diff_sol,
+                       double* z, const double* th, double* dz, int* iters_out) {
+  return ip_solve_impl(model_id, o, kappa_tol, diff_sol, z, th, dz, iters_out, NULL);
 }
 
 /* ----------------------------------------------------------------------------------------------
@@ -371,6 +377,31 @@ int od_oracle_step_full(const od_oracle_sim* s, double kappa_tol, int diff_sol, 
   double v1[NZMAX];
   for (int i = 0; i < nq; ++i) v1[i] = (x[nq + i] - x[i]) / s->h;
   return sim_step(s, kappa_tol, diff_sol, x + nq, v1, u, z, dz, iters);
+}
+
+/* the grad simulator's iterate and the clamp differentiate_solution! used, (nz+1) x B col-major like the device's
+ * hand-over workspace, plus its dq3/d(q1,q2,u1) -- input of the extended-precision arbiter (arbiter.c) */
+int od_oracle_grad_iterates(const od_oracle_sim* s, int B, const double* X, const double* U, double* Zg, double* G) {
+  const od_oracle_model* m = od_oracle_models[s->model_id];
+  const int nq = m->nq, nu = m->nu, nz = m->nz, n = 2 * nq, ngc = n + nu;
+  int bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(dynamic, 16)
+  for (int b = 0; b < B; ++b) {
+    const double* x = X + (size_t)n * b;
+    double v1[NZMAX], th[NTHMAX], z[NZMAX], dz[NZMAX * NTHMAX], reg = 0.0;
+    for (int i = 0; i < nq; ++i) { v1[i] = (x[nq + i] - x[i]) / s->h; th[i] = x[nq + i] - s->h * v1[i]; th[nq + i] = x[nq + i]; }
+    for (int i = 0; i < nu; ++i) th[2 * nq + i] = U[(size_t)nu * b + i];
+    for (int i = 0; i < m->nfric; ++i) th[2 * nq + nu + i] = s->fric[i];
+    th[2 * nq + nu + m->nfric] = s->h;
+    init_z(m, x + nq, z);
+    int it;
+    bad += !ip_solve_impl(s->model_id, &s->opts, s->opts.kappa_grad_tol, 1, z, th, dz, &it, &reg);
+    for (int i = 0; i < nz; ++i) Zg[(size_t)(nz + 1) * b + i] = z[i];
+    Zg[(size_t)(nz + 1) * b + nz] = reg;
+    for (int c = 0; c < ngc; ++c)
+      for (int i = 0; i < nq; ++i) G[(size_t)nq * ngc * b + i + nq * c] = dz[m->zq[i] + nz * c];
+  }
+  return bad;
 }
 
 /* ----------------------------------------------------------------------------------------------
@@ -556,3 +587,5 @@ int od_oracle_rollout(const od_oracle_sim* s, int B, int T, const double* x1, co
   }
   return bad;
 }
+
+#include "arbiter.c"

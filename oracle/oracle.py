@@ -224,6 +224,36 @@ def step_grad_batch(sim, X, U):
     return D.reshape(n, B, order="F"), DX.reshape(n, n, B, order="F"), DU.reshape(n, nu, B, order="F"), bad
 
 
+def grad_iterates(sim, X, U):
+    """the grad simulator's iterates: Zg (nz+1, B) (last row: the clamp differentiate_solution! used) and
+    G (nq, 2nq+nu, B) = dq3/d(q1, q2, u1) as this oracle computes it (dense partial-pivot LU in double)"""
+    d = dims(sim.model_id)
+    nq, nu, nz = d["nq"], d["nu"], d["nz"]
+    X = np.asfortranarray(X, dtype=np.float64)
+    U = np.asfortranarray(U, dtype=np.float64)
+    B = X.shape[1]
+    Zg = np.zeros((nz + 1) * B)
+    G = np.zeros(nq * (2 * nq + nu) * B)
+    bad = lib().od_oracle_grad_iterates(C.byref(sim), B, _p(X.reshape(-1, order="F")), _p(U.reshape(-1, order="F")), _p(Zg), _p(G))
+    return Zg.reshape(nz + 1, B, order="F"), G.reshape(nq, 2 * nq + nu, B, order="F"), bad
+
+
+def arbiter_dq3(sim, X, U, Zg):
+    """EXTENDED-PRECISION ARBITER (arbiter.c): dq3/d(q1, q2, u1) = rows q of -rz(z; reg)^{-1} rtheta(z) at the given
+    iterates Zg (nz+1, B), solved in IEEE binary128 -> G (nq, 2nq+nu, B), cond (B,) = ||rz||_inf ||rz^-1||_inf"""
+    d = dims(sim.model_id)
+    nq, nu, nz = d["nq"], d["nu"], d["nz"]
+    X = np.asfortranarray(X, dtype=np.float64)
+    U = np.asfortranarray(U, dtype=np.float64)
+    Zg = np.asfortranarray(Zg, dtype=np.float64)
+    B = X.shape[1]
+    G = np.zeros(nq * (2 * nq + nu) * B)
+    cond = np.zeros(B)
+    lib().od_arbiter_dq3_batch(C.byref(sim), B, _p(X.reshape(-1, order="F")), _p(U.reshape(-1, order="F")),
+                               _p(Zg.reshape(-1, order="F")), _p(G), _p(cond))
+    return G.reshape(nq, 2 * nq + nu, B, order="F"), cond
+
+
 def rollout(sim, x1, U, grads=True, bufs=None):
     """x1: (2nq,B); U: (nu,T,B) -> X (2nq,T+1,B), A (2nq,2nq,T,B), Bm (2nq,nu,T,B), nbad.
     `bufs` (a dict, filled on first use) lets a caller time the solves without the page faults of fresh output arrays."""

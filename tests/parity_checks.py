@@ -2,11 +2,14 @@
 the GPU tier (-m gpu, the shipped HIP library through the C ABI).  `lib` decides which.
 
 Tolerances (BASELINE.json north_star): states 1e-6 relative, implicit gradients 1e-4 relative.
-Gradients: the reference algorithm's own Jacobian is numerically singular at converged contact
-modes (inactive / sticking friction cones carry variables of size ~1e-23 whose ratios enter the
-implicit-function solve, DESIGN.md "gradient noise floor"), so two correct implementations agree to
-~1e-14 typically and to ~1e-4 on isolated samples; the checks assert the 1e-4 bound on >= 99.8 % of
-the samples, a 5e-3 cap on the rest and a 1e-9 median."""
+Gradients are held to the bar against an EXTENDED-PRECISION ARBITER (oracle/arbiter.c: the same
+dz = -rz^{-1} rtheta solved in IEEE binary128 at a given iterate) on 100 % of the converged knots:
+  * the device's gradient against the exact one AT THE DEVICE'S OWN ITERATE (od_get_grad_iterates):  <= 1e-8;
+  * device against oracle: <= 1e-4 + what the exact gradients at the two iterates differ by.
+At converged contact modes rz has condition numbers up to 1e27 and the two implementations' iterates differ by
+~1e-11 (both inside r_tol): the exact gradient itself then moves by up to 1e-2 between the two iterates -- measured,
+profiles/r2_parity_sweep.json -- while each solver reproduces its own exact gradient to 1e-12.  Where no iterate is
+available (rollout knots, callbacks) assert_grad_close keeps the statistical form (1e-4 on >= 99.8 %, 1e-9 median)."""
 import numpy as np
 import torch
 
@@ -35,10 +38,45 @@ def make_sim(oracle, name, **over):
 
 
 def assert_grad_close(G, Go, ok, what):
+    """statistical form, for comparisons without recorded iterates (see module docstring)"""
     rel = W.grad_rel_err(G, Go)[ok]
     assert np.median(rel) < 1e-9, (what, np.median(rel))
     assert (rel < GRAD_TOL).mean() >= 0.998, (what, np.sort(rel)[-5:])
-    assert rel.max() < 5e-3, (what, rel.max())
+
+
+EXACT_TOL = 1e-8
+
+
+def exact_gradient_errors(oracle, im, name, X, U, Gd):
+    """Gd: (nq, 2nq+nu, B) = the device's dq3/d(q1,q2,u1) of the LAST step_grad call on `im` for (X, U).
+    -> dict of per-knot relative errors (scale = max |exact gradient| of the knot):
+       dev = |device - exact at the device's iterate|, orc = |oracle - exact at the oracle's iterate|,
+       cross = |device - oracle|, explained = |exact at device's iterate - exact at oracle's iterate|, cond"""
+    B = X.shape[1]
+    sim = make_sim(oracle, name)
+    Zd = im.grad_iterates(B).cpu().numpy()
+    Zo, Go, _ = oracle.grad_iterates(sim, X, U)
+    Ed, cd = oracle.arbiter_dq3(sim, X, U, Zd)
+    Eo, co = oracle.arbiter_dq3(sim, X, U, Zo)
+    sc = np.maximum(np.abs(Eo).reshape(-1, B).max(0), 1e-12)
+    f = lambda a, b: np.abs(a - b).reshape(-1, B).max(0) / sc
+    return dict(dev=f(Gd, Ed), orc=f(Go, Eo), cross=f(Gd, Go), explained=f(Ed, Eo), cond=cd,
+                iterate_diff=np.abs(Zd - Zo)[:-1].max(0))
+
+
+def assert_grad_exact(oracle, im, name, X, U, DX, DU, ok, what):
+    """the 1e-4 bar on 100 % of the converged knots, arbitrated in binary128"""
+    nq = X.shape[0] // 2
+    Gd = np.concatenate([DX[nq:], DU[nq:]], 1)
+    e = exact_gradient_errors(oracle, im, name, X, U, Gd)
+    fin = ok & np.isfinite(e["dev"]) & np.isfinite(e["explained"])       # an exactly singular rz has no gradient at all
+    assert fin.sum() >= ok.sum() - max(1, ok.sum() // 5000), (what, ok.sum() - fin.sum())
+    assert e["dev"][fin].max() < EXACT_TOL, (what, "device vs exact at its own iterate", e["dev"][fin].max())
+    assert e["orc"][fin].max() < EXACT_TOL, (what, "oracle vs exact at its own iterate", e["orc"][fin].max())
+    excess = e["cross"][fin] - 2.0 * e["explained"][fin]
+    assert excess.max() < GRAD_TOL, (what, "device vs oracle beyond what their iterates explain", excess.max())
+    assert np.median(e["cross"][fin]) < 1e-9
+    return e
 
 
 def check_step_grad(oracle, lib, device, name, B):
@@ -52,7 +90,7 @@ def check_step_grad(oracle, lib, device, name, B):
     assert (st[ok] & 4).all()
     srel = np.abs(D - Do).max(0) / np.maximum(1e-2, np.abs(Do).max(0))
     assert srel[ok].max() < STATE_TOL, srel[ok].max()
-    assert_grad_close(np.concatenate([DX, DU], 1), np.concatenate([DXo, DUo], 1), ok, name)
+    assert_grad_exact(oracle, im, name, X, U, DX, DU, ok, name)
     # structure of fx: [0 I] on top (src/dynamics.jl:105-108), du top rows zero
     nq = X.shape[0] // 2
     assert np.all(DX[:nq, :nq] == 0) and np.all(DX[:nq, nq:] == np.eye(nq)[:, :, None])
@@ -142,20 +180,34 @@ def check_bundle(oracle, lib, device, name, B, N):
     X, U = W.knots(name, B, seed=31)
     m = models.BY_NAME[name]
     gb = gbm.GradientBundle(m, N=N, eps=1e-4, seed=5)
+    nq = m.nq
+    sampled = np.abs(gb.eta).sum(1) > 0
+    # A zero-order fit divides state differences by eps = 1e-4, so it amplifies whatever the two solvers leave
+    # unconverged by 1e4: at the reference's r_tol = 1e-8 that alone is ~1e-4 relative.  The fit itself is held to the
+    # 1e-4 bar with both solvers converged to r_tol = 1e-12 (same samples, same least-squares problem) ...
+    imt = make_im(name, lib, device, info=gb)
+    imt.set_options(r_tol=1e-12)
+    dzt, stt = gbm.gradient_batch(imt, gb, torch.tensor(X), torch.tensor(U))
+    dzt, stt = dzt.cpu().numpy(), stt.cpu().numpy()
+    simt = make_sim(oracle, name, r_tol=1e-12)
+    ncmp = 0
+    for b in range(min(B, 6)):
+        ok, dzo = oracle.gradient_bundle(simt, gb.eta, X[:nq, b], X[nq:, b], U[:, b])
+        if not (ok and stt[b] == 1 and sampled.all()):
+            continue
+        ncmp += 1
+        assert np.abs(dzt[:, :, b] - dzo).max() < GRAD_TOL * max(1.0, np.abs(dzo).max()), np.abs(dzt[:, :, b] - dzo).max()
+    # ... and at the reference's own tolerance to the amplified convergence noise (r_tol / eps, with a factor for the sum
+    # over samples)
     im = make_im(name, lib, device, info=gb)
     dz, st = gbm.gradient_batch(im, gb, torch.tensor(X), torch.tensor(U))
     dz, st = dz.cpu().numpy(), st.cpu().numpy()
     sim = make_sim(oracle, name)
-    nq = m.nq
-    sampled = np.abs(gb.eta).sum(1) > 0
     for b in range(min(B, 6)):
         ok, dzo = oracle.gradient_bundle(sim, gb.eta, X[:nq, b], X[nq:, b], U[:, b])
         if not (ok and st[b] == 1 and sampled.all()):
             continue
-        # a zero-order fit divides O(1e-10) state differences by eps=1e-4: both sides carry the
-        # solver's own convergence noise (r_tol=1e-8 / eps), so compare loosely, and against each
-        # other's noise-free part via the analytic gradient below
-        assert np.abs(dz[:, :, b] - dzo).max() < 5e-3 * max(1.0, np.abs(dzo).max())
+        assert np.abs(dz[:, :, b] - dzo).max() < 10 * (1e-8 / 1e-4) * max(1.0, np.abs(dzo).max())
     # the bundle approximates the analytic implicit gradient (smooth branch): sanity, loose
     D, DX, DU, st2, it = im.step_grad(torch.tensor(X), torch.tensor(U))
     G = np.concatenate([DX.cpu().numpy()[nq:], DU.cpu().numpy()[nq:]], 1)
@@ -251,8 +303,13 @@ def check_scalar_callbacks(oracle, lib, device, name):
         if not so:
             continue
         assert np.abs(d - do).max() < STATE_TOL * max(1, np.abs(do).max())
-        assert np.abs(dx - dxo).max() < 5e-3 * max(1, np.abs(dxo).max())
-        assert np.abs(du - duo).max() < 5e-3 * max(1, np.abs(duo).max())
+        # the callbacks return what the batched entry point returns for the same knot (held to the 1e-4 bar against the
+        # binary128 arbiter in check_step_grad); against the oracle directly: 1e-4
+        Db, DXb, DUb, stb, itb = [t.cpu().numpy() for t in im.step_grad(torch.tensor(X[:, b:b + 1]), torch.tensor(U[:, b:b + 1]))]
+        assert np.array_equal(d, Db[:, 0])
+        assert np.abs(dx[nq:] - DXb[nq:, :, 0]).max() <= 1e-12 * max(1, np.abs(dxo).max()) and np.abs(du[nq:] - DUb[nq:, :, 0]).max() <= 1e-12 * max(1, np.abs(duo).max())
+        assert np.abs(dx - dxo).max() < GRAD_TOL * max(1, np.abs(dxo).max())
+        assert np.abs(du - duo).max() < GRAD_TOL * max(1, np.abs(duo).max())
     q = dyn.state_to_configuration([X[:, 0], np.r_[X[nq:, 0], X[:nq, 0]]])
     assert len(q) == 3 and np.all(q[0] == X[:nq, 0]) and np.all(q[1] == X[nq:, 0]) and np.all(q[2] == X[:nq, 0])
 
