@@ -78,6 +78,9 @@ int od_set_friction(od_handle h, const double* mu, int n);
 /* RocketInfo.u_max (src/models/rocket/dynamics.jl:8) */
 int od_set_u_max(od_handle h, double u_max);
 int od_set_layout(od_handle h, int layout);
+/* A handle runs on one stream at a time (its gradient hand-over and staging workspaces are reused by consecutive
+ * calls): changing the stream first waits for the work queued on the previous one.  Use one handle per stream for
+ * concurrency. */
 int od_set_stream(od_handle h, void* hip_stream);
 /* launch tuning of the solve pass.  ppw: problems per 64-lane wavefront (power of two <= 64, 0 = automatic)
  * -- a wavefront is as slow as its slowest lane, so small batches are spread over more wavefronts.

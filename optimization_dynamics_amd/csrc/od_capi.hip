@@ -609,9 +609,22 @@ int od_raw_grad_dims(int model, int* nzq, int* ngc) {
   return OD_OK;
 }
 
+// InteriorPointOptions the solver can run with: a line search needs one trial (it keeps the last one whatever happens),
+// tolerances are positive numbers (NaN fails every comparison here), undercut >= 1 or INFINITY
+static const char* bad_options(const od_options* o) {
+  if (!(o->r_tol > 0) || !(o->kappa_eval_tol > 0) || !(o->kappa_grad_tol > 0)) return "r_tol, kappa_eval_tol and kappa_grad_tol must be positive";
+  if (o->max_iter < 0) return "max_iter must be >= 0";
+  if (o->max_ls < 1) return "max_ls must be >= 1";
+  if (!(o->eps_min >= 0) || !(o->eps_min <= 1) || !(o->kappa_reg >= 0) || !(o->gamma_reg >= 0)) return "eps_min in [0, 1], kappa_reg >= 0, gamma_reg >= 0";
+  if (!(o->undercut > 0)) return "undercut must be positive (INFINITY allowed)";
+  return nullptr;
+}
+
 int od_create(int model, int dtype, const od_options* opts, double dt, od_handle* out) {
   const ModelVT* vt = vt_of(model);
   if (!vt || !out) return fail(OD_ERR_INVALID, "od_create: bad arguments");
+  if (!(dt > 0)) return fail(OD_ERR_INVALID, "od_create: the time step must be positive");
+  if (opts) { if (const char* why = bad_options(opts)) return fail(OD_ERR_INVALID, std::string("od_create: ") + why); }
   if (dtype != OD_F64 && dtype != OD_F32) return fail(OD_ERR_INVALID, "od_create: bad dtype");
   if (dtype == OD_F32 && !vt->raw32)
     return fail(OD_ERR_UNSUPPORTED, "od_create: OD_F32 is instantiated for the rocket models only");
@@ -648,6 +661,7 @@ int od_destroy(od_handle h) {
 
 int od_set_options(od_handle h, const od_options* o) {
   if (!h || !o) return fail(OD_ERR_INVALID, "od_set_options: bad arguments");
+  if (const char* why = bad_options(o)) return fail(OD_ERR_INVALID, std::string("od_set_options: ") + why);
   h->opts = *o;
   return OD_OK;
 }
@@ -678,7 +692,12 @@ int od_set_layout(od_handle h, int layout) {
 }
 int od_set_stream(od_handle h, void* s) {
   if (!h) return fail(OD_ERR_INVALID, "od_set_stream: null handle");
-  h->stream = (hipStream_t)s;
+  if (h->stream != (hipStream_t)s) {
+    // the handle's workspaces (gradient hand-over, staging) are shared by consecutive calls: a handle works on one
+    // stream at a time, so work queued on the old stream finishes before the new one may reuse them
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(OD_ERR_HIP, "od_set_stream: hipStreamSynchronize of the previous stream failed");
+    h->stream = (hipStream_t)s;
+  }
   return OD_OK;
 }
 int od_set_cooperative(od_handle h, int mode) {

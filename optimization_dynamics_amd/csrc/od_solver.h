@@ -283,7 +283,9 @@ OD_HD bool ls_trial(const T* th, const T* pre, T* tr, const T* z, const T* D, T 
 template <class M, class T>
 OD_HD void line_search(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z, const T* D, T& alpha, T* r, T& r_vio, T& k_vio) {
   T zc[M::NZ];
-  T r_c = T(0), k_c = T(0);
+#pragma unroll
+  for (int i = 0; i < M::NZ; ++i) zc[i] = z[i];        // (max_ls < 1 is rejected at the API; never copy garbage back)
+  T r_c = r_vio, k_c = k_vio;
   const bool par = parallel_line_search<M>() && o.coop != 0;
   const int nseq = par ? od_min(2, o.max_ls) : o.max_ls;
   bool done = false;

@@ -110,7 +110,7 @@ class ImplicitDynamics:
 
     def grad_iterates(self, K):
         """(nz+1, K): the iterates (and, last row, orthant clamps) at which the last step_grad / rollout call on this
-        handle took its K implicit gradients -- diagnostics for the extended-precision arbiter (oracle/arbiter.c)"""
+        handle took its K implicit gradients -- diagnostics: a checker can recompute dz = -rz^{-1} rtheta at exactly those points"""
         self._use_current_stream()
         nz = self.lib.model_dims(self.model.name)["nz"]
         out = self._new(nz + 1, K)

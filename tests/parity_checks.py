@@ -483,6 +483,14 @@ def check_live_setters(lib, device):
     assert o.max_iter == 3 and o.kappa_eval_tol == 1e-2 and o.r_tol == 1e-8
     D, st, it = im.step(Xt, Ut)
     assert (it[0] <= 3).all()
+    # options the solver cannot run with are rejected (OD_ERR_INVALID), the handle keeps its previous ones
+    import ctypes as C
+    for bad in (dict(max_ls=0), dict(max_iter=-1), dict(r_tol=0.0), dict(kappa_eval_tol=float("nan")), dict(undercut=0.0), dict(eps_min=2.0)):
+        o2 = im.get_options()
+        for k, v in bad.items():
+            setattr(o2, k, v)
+        assert lib.cdll.od_set_options(im._h, C.byref(o2)) == -1, bad
+    assert im.get_options().max_iter == 3 and im.get_options().max_ls == o.max_ls
     info = rk.RocketInfo(models.rocket, 12.5, 0.05, device=device, lib=lib)
     u = torch.tensor([[0.0], [0.0], [20.0]])
     assert abs(info.project(u, grads=False)[0][2, 0].item() - 12.5) < 2e-3
