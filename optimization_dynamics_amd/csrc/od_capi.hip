@@ -438,6 +438,7 @@ int check_mech(od_handle_s* h, const char* fn) {
   if (!h) return fail(OD_ERR_INVALID, std::string(fn) + ": null handle");
   if (h->vt->kind != 0) return fail(OD_ERR_UNSUPPORTED, std::string(fn) + ": model is not a mechanical (q1,q2,u) model");
   if (h->dtype != OD_F64) return fail(OD_ERR_UNSUPPORTED, std::string(fn) + ": mechanical models are instantiated for OD_F64 only");
+  if (!(h->h > 0)) return fail(OD_ERR_INVALID, std::string(fn) + ": the handle has no positive time step");
   return OD_OK;
 }
 
@@ -623,7 +624,7 @@ static const char* bad_options(const od_options* o) {
 int od_create(int model, int dtype, const od_options* opts, double dt, od_handle* out) {
   const ModelVT* vt = vt_of(model);
   if (!vt || !out) return fail(OD_ERR_INVALID, "od_create: bad arguments");
-  if (!(dt > 0)) return fail(OD_ERR_INVALID, "od_create: the time step must be positive");
+  if (!(dt >= 0)) return fail(OD_ERR_INVALID, "od_create: the time step must not be negative (0: a handle for od_ip_solve only)");
   if (opts) { if (const char* why = bad_options(opts)) return fail(OD_ERR_INVALID, std::string("od_create: ") + why); }
   if (dtype != OD_F64 && dtype != OD_F32) return fail(OD_ERR_INVALID, "od_create: bad dtype");
   if (dtype == OD_F32 && !vt->raw32)
