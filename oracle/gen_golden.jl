@@ -2,12 +2,27 @@
 # IterativeLQR.jl as pinned by its Project.toml).  Cannot run in the build environment (no Julia);
 # run it where Julia >= 1.6 and the packages exist:
 #
+#     python tests/golden/export_inputs.py                       # writes tests/golden/inputs/*.bin
 #     julia --project=/path/to/optimization_dynamics oracle/gen_golden.jl tests/golden/inputs tests/golden/reference
+#     python -m pytest tests/test_reference_golden.py            # oracle vs reference (CPU), -m gpu: HIP path vs reference
 #
-# Inputs: little-endian Float64 files <model>_X.bin (2nq x B), <model>_U.bin (nu x B) written by
-# `python tests/golden/export_inputs.py` from tests/golden/oracle_v1.npz.  Outputs, same layout as the
-# npz arrays: <model>_D.bin (2nq x B), <model>_DX.bin (2nq x 2nq x B), <model>_DU.bin (2nq x nu x B).
+# Every array is a little-endian Float64 file, column-major, in the layout of tests/golden/oracle_v1.npz.
+#
+#   mechanical models (f, fx, fu: src/dynamics.jl:81-128)
+#     in : <model>_X.bin (2nq x B), <model>_U.bin (nu x B)
+#     out: <model>_D.bin (2nq x B), <model>_DX.bin (2nq x 2nq x B), <model>_DU.bin (2nq x nu x B),
+#          <model>_IT.bin (3 x B: interior-point iterations of the f, fx and fu solves; -1 if the field is not there),
+#          <model>_ST.bin (3 x B: 1 = the solver reported success, 0 = failure, -1 = not observable)
+#   rocket (src/models/rocket/dynamics.jl:101-268), u_max = 12.5, h = 0.05 (examples/rocket.jl:16,19)
+#     in : rocket_X.bin (12 x B), rocket_U.bin (3 x B)
+#     out: rocket_Y.bin, rocket_DX.bin (12 x 12 x B), rocket_DU.bin (12 x 3 x B)            f/fx/fu_rocket
+#          rocket_Yp.bin, rocket_DXp.bin, rocket_DUp.bin                                    f/fx/fu_rocket_proj
+#          rocket_UP.bin (3 x B), rocket_DP.bin (3 x 3 x B)                                 soc_projection(_gradient)
+#   gradient bundle (src/gradient_bundle.jl:87-104) with the exported perturbations eta
+#     in : bundle_<model>_X.bin (2nq x B), bundle_<model>_U.bin (nu x B), bundle_<model>_eta.bin ((2nq+nu) x N)
+#     out: bundle_<model>_DZ.bin (nq x (2nq+nu) x B)
 using OptimizationDynamics
+using LinearAlgebra
 const RoboDojo = OptimizationDynamics.RoboDojo
 
 indir, outdir = ARGS[1], ARGS[2]
@@ -15,6 +30,64 @@ mkpath(outdir)
 
 readmat(path, n) = (v = reinterpret(Float64, read(path)); reshape(collect(v), n, :))
 writearr(path, a) = write(path, reinterpret(UInt8, vec(Float64.(a))))
+
+# iteration count / status of the last solve of a simulator, where the installed RoboDojo exposes them
+ip_of(sim) = hasproperty(sim, :ip) ? sim.ip : nothing
+iters_of(sim) = (ip = ip_of(sim); ip !== nothing && hasproperty(ip, :iterations) ? Float64(ip.iterations) : -1.0)
+function status_of(sim)
+    ip = ip_of(sim)
+    ip === nothing && return -1.0
+    o = ip.opts
+    (hasproperty(ip, :r) && hasproperty(ip, :idx)) || return -1.0
+    try
+        rv = RoboDojo.residual_violation(ip, ip.r)
+        kv = RoboDojo.bilinear_violation(ip, ip.r)
+        return (rv < o.r_tol && kv < o.κ_tol) ? 1.0 : 0.0
+    catch
+        return -1.0
+    end
+end
+
+function run_mech(name, im_dyn, nq, nu)
+    X = readmat(joinpath(indir, name * "_X.bin"), 2nq)
+    U = readmat(joinpath(indir, name * "_U.bin"), nu)
+    B = size(X, 2)
+    D = zeros(2nq, B); DX = zeros(2nq, 2nq, B); DU = zeros(2nq, nu, B); IT = fill(-1.0, 3, B); ST = fill(-1.0, 3, B)
+    for b = 1:B
+        d = zeros(2nq); dx = zeros(2nq, 2nq); du = zeros(2nq, nu)
+        f(d, im_dyn, X[:, b], U[:, b], zeros(0));   IT[1, b] = iters_of(im_dyn.eval_sim); ST[1, b] = status_of(im_dyn.eval_sim)
+        fx(dx, im_dyn, X[:, b], U[:, b], zeros(0)); IT[2, b] = iters_of(im_dyn.grad_sim); ST[2, b] = status_of(im_dyn.grad_sim)
+        fu(du, im_dyn, X[:, b], U[:, b], zeros(0)); IT[3, b] = iters_of(im_dyn.grad_sim); ST[3, b] = status_of(im_dyn.grad_sim)
+        D[:, b] = d; DX[:, :, b] = dx; DU[:, :, b] = du
+    end
+    writearr(joinpath(outdir, name * "_D.bin"), D)
+    writearr(joinpath(outdir, name * "_DX.bin"), DX)
+    writearr(joinpath(outdir, name * "_DU.bin"), DU)
+    writearr(joinpath(outdir, name * "_IT.bin"), IT)
+    writearr(joinpath(outdir, name * "_ST.bin"), ST)
+end
+
+# gradient! with the exported eta.  The constructor sizes q1η / q2η / u1η with the module globals nq, nu (the rocket's
+# 12 and 3 after `using`, src/gradient_bundle.jl:79-81), so they are resized to the model's here; nothing else changes.
+function run_bundle(name, im_dyn, model)
+    p = joinpath(indir, "bundle_" * name * "_X.bin")
+    isfile(p) || return
+    nq, nu = model.nq, model.nu
+    X = readmat(p, 2nq); U = readmat(joinpath(indir, "bundle_" * name * "_U.bin"), nu)
+    eta = readmat(joinpath(indir, "bundle_" * name * "_eta.bin"), 2nq + nu)
+    N = size(eta, 2); B = size(X, 2)
+    gb = OptimizationDynamics.GradientBundle(model, N=N, ϵ=1.0e-4)
+    resize!(gb.q1η, nq); resize!(gb.q2η, nq); resize!(gb.u1η, nu)
+    for i = 1:N
+        gb.ls.η[i] .= eta[:, i]
+    end
+    DZ = zeros(nq, 2nq + nu, B)
+    for b = 1:B
+        gb.ls.θ .= 0.0
+        DZ[:, :, b] = OptimizationDynamics.gradient!(im_dyn.eval_sim, gb, X[1:nq, b], X[nq+1:2nq, b], U[:, b])
+    end
+    writearr(joinpath(outdir, "bundle_" * name * "_DZ.bin"), DZ)
+end
 
 configs = Dict(
     "acrobot_impact" => (acrobot_impact, 0.05, r_acrobot_impact_func, rz_acrobot_impact_func, rθ_acrobot_impact_func, 1.0e-4, 1.0e-3),
@@ -24,42 +97,42 @@ configs = Dict(
     "planar_push" => (planarpush, 0.1, r_pp_func, rz_pp_func, rθ_pp_func, 1.0e-4, 1.0e-2),
 )
 
-function run_model(name, model, h, r, rz, rθ, κe, κg)
-    nq, nu = model.nq, model.nu
-    X = readmat(joinpath(indir, name * "_X.bin"), 2nq)
-    U = readmat(joinpath(indir, name * "_U.bin"), nu)
-    B = size(X, 2)
-    im_dyn = ImplicitDynamics(model, h, eval(r), eval(rz), eval(rθ); r_tol=1.0e-8, κ_eval_tol=κe, κ_grad_tol=κg)
-    D = zeros(2nq, B); DX = zeros(2nq, 2nq, B); DU = zeros(2nq, nu, B)
-    for b = 1:B
-        d = zeros(2nq); dx = zeros(2nq, 2nq); du = zeros(2nq, nu)
-        f(d, im_dyn, X[:, b], U[:, b], zeros(0))
-        fx(dx, im_dyn, X[:, b], U[:, b], zeros(0))
-        fu(du, im_dyn, X[:, b], U[:, b], zeros(0))
-        D[:, b] = d; DX[:, :, b] = dx; DU[:, :, b] = du
-    end
-    writearr(joinpath(outdir, name * "_D.bin"), D)
-    writearr(joinpath(outdir, name * "_DX.bin"), DX)
-    writearr(joinpath(outdir, name * "_DU.bin"), DU)
-end
-
 cartpole_friction.friction .= [0.35; 0.35]        # examples/cartpole.jl:21
-for (name, c) in configs
-    run_model(name, c...)
+for (name, (model, h, r, rz, rθ, κe, κg)) in configs
+    im_dyn = ImplicitDynamics(model, h, eval(r), eval(rz), eval(rθ); r_tol=1.0e-8, κ_eval_tol=κe, κ_grad_tol=κg)
+    run_mech(name, im_dyn, model.nq, model.nu)
+    run_bundle(name, im_dyn, model)
 end
 
 # hopper: residual expressions come from RoboDojo (examples/hopper.jl:38-42)
 let hopper = RoboDojo.hopper
-    nq, nu = hopper.nq, hopper.nu
-    X = readmat(joinpath(indir, "hopper_X.bin"), 2nq); U = readmat(joinpath(indir, "hopper_U.bin"), nu)
-    B = size(X, 2)
     im_dyn = ImplicitDynamics(hopper, 0.05, eval(RoboDojo.residual_expr(hopper)), eval(RoboDojo.jacobian_var_expr(hopper)),
         eval(RoboDojo.jacobian_data_expr(hopper)); r_tol=1.0e-8, κ_eval_tol=1.0e-4, κ_grad_tol=1.0e-3, nc=4, nb=2)
-    D = zeros(2nq, B); DX = zeros(2nq, 2nq, B); DU = zeros(2nq, nu, B)
-    for b = 1:B
-        d = zeros(2nq); dx = zeros(2nq, 2nq); du = zeros(2nq, nu)
-        f(d, im_dyn, X[:, b], U[:, b], zeros(0)); fx(dx, im_dyn, X[:, b], U[:, b], zeros(0)); fu(du, im_dyn, X[:, b], U[:, b], zeros(0))
-        D[:, b] = d; DX[:, :, b] = dx; DU[:, :, b] = du
-    end
-    writearr(joinpath(outdir, "hopper_D.bin"), D); writearr(joinpath(outdir, "hopper_DX.bin"), DX); writearr(joinpath(outdir, "hopper_DU.bin"), DU)
+    run_mech("hopper", im_dyn, hopper.nq, hopper.nu)
+    run_bundle("hopper", im_dyn, hopper)
 end
+
+# rocket (examples/rocket.jl:16-23)
+let
+    info = RocketInfo(rocket, 12.5, 0.05,
+        eval(r_rocket_func), eval(rz_rocket_func), eval(rθ_rocket_func),
+        eval(r_proj_func), eval(rz_proj_func), eval(rθ_proj_func))
+    X = readmat(joinpath(indir, "rocket_X.bin"), 12); U = readmat(joinpath(indir, "rocket_U.bin"), 3)
+    B = size(X, 2)
+    Y = zeros(12, B); DX = zeros(12, 12, B); DU = zeros(12, 3, B)
+    Yp = zeros(12, B); DXp = zeros(12, 12, B); DUp = zeros(12, 3, B); UP = zeros(3, B); DP = zeros(3, 3, B)
+    for b = 1:B
+        x, u = X[:, b], U[:, b]
+        d = zeros(12); dx = zeros(12, 12); du = zeros(12, 3)
+        f_rocket(d, info, x, u, zeros(0)); fx_rocket(dx, info, x, u, zeros(0)); fu_rocket(du, info, x, u, zeros(0))
+        Y[:, b] = d; DX[:, :, b] = dx; DU[:, :, b] = du
+        f_rocket_proj(d, info, x, u, zeros(0)); fx_rocket_proj(dx, info, x, u, zeros(0)); fu_rocket_proj(du, info, x, u, zeros(0))
+        Yp[:, b] = d; DXp[:, :, b] = dx; DUp[:, :, b] = du
+        UP[:, b] = copy(OptimizationDynamics.soc_projection(u, info))
+        DP[:, :, b] = copy(OptimizationDynamics.soc_projection_gradient(u, info))
+    end
+    for (n, a) in (("Y", Y), ("DX", DX), ("DU", DU), ("Yp", Yp), ("DXp", DXp), ("DUp", DUp), ("UP", UP), ("DP", DP))
+        writearr(joinpath(outdir, "rocket_" * n * ".bin"), a)
+    end
+end
+println("reference vectors written to ", outdir)
