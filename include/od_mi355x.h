@@ -206,6 +206,19 @@ int od_rocket_rollout(od_handle h, long B, int T, int nalpha, const void* alphas
 int od_f_host(od_handle h, const double* x, const double* u, double* d);
 int od_fx_host(od_handle h, const double* x, const double* u, double* dx);
 int od_fu_host(od_handle h, const double* x, const double* u, double* du);
+/* f, fx and fu of one knot from ONE solve (the reference's three callbacks each solve again, src/dynamics.jl:88,103,123);
+ * any of d, dx, du may be NULL.  A Julia closure triple can call this once per (x, u) and serve fx / fu from the result. */
+int od_ffxfu_host(od_handle h, const double* x, const double* u, double* d, double* dx, double* du);
+/* the scalar rocket entry points on host vectors, OD_ROCKET_DYNAMICS handle (src/models/rocket/dynamics.jl):
+ * project = 0: f_rocket / fx_rocket / fu_rocket (:101-164); project = 1: f/fx/fu_rocket_proj (:215-268, du includes the
+ * chain product with the projection gradient).  y 12, dx 12 x 12, du 12 x 3 col-major, uproj 3; outputs may be NULL. */
+int od_rocket_host(od_handle h, int project, const double* x, const double* u, double* y, double* dx, double* du,
+                   double* uproj, int* status);
+/* soc_projection (duproj = NULL) / soc_projection_gradient (:168-214) for one u (3) -> uproj (3), duproj (3 x 3) */
+int od_soc_project_host(od_handle h, const double* u, double* uproj, double* duproj, int* status);
+/* gradient!(sim, gb, q1, q2, u1) for one knot on host vectors (src/gradient_bundle.jl:87-104): x = [q1; q2] (2nq),
+ * eta (2nq+nu) x N col-major (gb.ls.eta), dz nq x (2nq+nu) col-major (gb.dz) */
+int od_bundle_grad_host(od_handle h, int N, const double* x, const double* u, const double* eta, double* dz, int* status);
 
 #ifdef __cplusplus
 }

@@ -1,10 +1,25 @@
-# ccall shim over libod_mi355x.so keeping the reference's ImplicitDynamics f / fx / fu API
-# (src/dynamics.jl).  NOT exercised in the build environment (no Julia there); the identical entry
-# points are exercised through ctypes by tests/.  See INTEGRATION.md.
+# ccall shim over libod_mi355x.so that keeps the reference's exported API (src/OptimizationDynamics.jl:32-34,75-79):
+#
+#   ImplicitDynamics(model, h, r, rz, rθ; T, r_tol, κ_eval_tol, κ_grad_tol, no_impact, no_friction, n, m, d, nc, nb, info)
+#   f / fx / fu (src/dynamics.jl:81-128)             state_to_configuration (:131-145)
+#   GradientBundle(model; N, ϵ), fx_gb / fu_gb (src/gradient_bundle.jl:26-147)
+#   RocketInfo(rocket, u_max, h, r..., r_proj...), f_rocket / fx_rocket / fu_rocket, f/fx/fu_rocket_proj,
+#   soc_projection, soc_projection_gradient (src/models/rocket/dynamics.jl:12-268)
+#
+# Every scalar callback is one ccall with host vectors (od_*_host: copy in, launch, copy out, synchronise), so neither
+# AMDGPU.jl nor any device array is needed; the batched entry points at the end take device arrays.
+# The generated residual functions the reference passes around (r, rz, rθ) are accepted and ignored: the device code
+# was generated from the same residual statements (optimization_dynamics_amd/codegen).
+# NOT exercised in the build environment (no Julia there); tests/test_julia_shim_calls.py replays, through ctypes,
+# the exact call sequence of every function below.  See INTEGRATION.md.
 module OptimizationDynamicsMI355X
 
-export ImplicitDynamicsMI355X, f, fx, fu, state_to_configuration, od_step_grad!, od_rollout!,
-       RocketInfoMI355X, od_rocket!, od_soc_project!, od_step_full!, model_indices
+using LinearAlgebra
+
+export ImplicitDynamics, f, fx, fu, state_to_configuration, GradientBundle, fx_gb, fu_gb,
+       RocketInfo, f_rocket, fx_rocket, fu_rocket, f_rocket_proj, fx_rocket_proj, fu_rocket_proj,
+       soc_projection, soc_projection_gradient, ffxfu!,
+       od_step_grad!, od_rollout!, od_rollout_compact!, od_rocket!, od_soc_project!, od_step_full!, model_indices
 
 const LIB = get(ENV, "OD_MI355X_LIB", joinpath(@__DIR__, "..", "optimization_dynamics_amd", "libod_mi355x.so"))
 
@@ -23,55 +38,110 @@ function check(rc)
     error("libod_mi355x: " * unsafe_string(ccall((:od_last_error, LIB), Cstring, ())))
 end
 
-mutable struct ImplicitDynamicsMI355X
-    h::Ptr{Cvoid}
-    nq::Int; nu::Int
-    dx_buf::Matrix{Float64}; du_buf::Matrix{Float64}
-    idx_q1::Vector{Int}; idx_q2::Vector{Int}
+# model argument: a Symbol of MODEL_IDS, or the reference's model object (matched by its type name / fields)
+function model_symbol(model)
+    model isa Symbol && return model
+    n = lowercase(string(nameof(typeof(model))))
+    occursin("hopper", n) && return :hopper
+    occursin("planarpush", n) && return :planarpush
+    occursin("rocket", n) && return :rocket
+    if occursin("acrobot", n)
+        return (hasproperty(model, :nc) && model.nc == 0) ? :acrobot_nominal : :acrobot_impact
+    elseif occursin("cartpole", n)
+        return (hasproperty(model, :friction) && length(model.friction) > 0) ? :cartpole_friction : :cartpole_frictionless
+    end
+    error("unknown model $(typeof(model)); pass one of $(keys(MODEL_IDS))")
 end
 
-"ImplicitDynamics(model, h, …; r_tol, κ_eval_tol, κ_grad_tol) — src/dynamics.jl:51-79"
-function ImplicitDynamicsMI355X(model::Symbol, h::Float64; r_tol=1.0e-8, κ_eval_tol=1.0e-6, κ_grad_tol=1.0e-6)
-    id = MODEL_IDS[model]
+mutable struct ImplicitDynamics{I}
+    h::Ptr{Cvoid}
+    model::Any
+    nq::Int; nu::Int
+    n::Int; m::Int; d::Int; nc::Int; nb::Int        # bookkeeping keywords of the reference constructor
+    dx_buf::Matrix{Float64}; du_buf::Matrix{Float64}
+    idx_q1::Vector{Int}; idx_q2::Vector{Int}; idx_u1::Vector{Int}
+    info::I
+end
+
+"ImplicitDynamics(model, h, r, rz, rθ; ...) -- src/dynamics.jl:51-79 (option preset of get_simulator, :16-33)"
+function ImplicitDynamics(model, h, r_func=nothing, rz_func=nothing, rθ_func=nothing;
+        T=1, r_tol=1.0e-8, κ_eval_tol=1.0e-6, κ_grad_tol=1.0e-6,
+        no_impact=false, no_friction=false,
+        n=nothing, m=nothing, d=0, nc=nothing, nb=nothing, info=nothing)
+    sym = model_symbol(model)
+    id = MODEL_IDS[sym]
     dims = [Ref{Cint}(0) for _ in 1:5]
     check(ccall((:od_model_dims, LIB), Cint, (Cint, Ref{Cint}, Ref{Cint}, Ref{Cint}, Ref{Cint}, Ref{Cint}), id, dims...))
     nq, nu = Int(dims[1][]), Int(dims[2][])
-    o = Ref(ODOptions(r_tol, κ_eval_tol, κ_grad_tol, 100, 25, 0.25, 1.0e-3, 0.1, Inf))   # get_simulator preset, src/dynamics.jl:25-33
+    o = Ref(ODOptions(r_tol, κ_eval_tol, κ_grad_tol, 100, 25, 0.25, 1.0e-3, 0.1, Inf))   # src/dynamics.jl:25-33
     hd = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:od_create, LIB), Cint, (Cint, Cint, Ref{ODOptions}, Cdouble, Ref{Ptr{Cvoid}}), id, 0, o, h, hd))
-    m = ImplicitDynamicsMI355X(hd[], nq, nu, zeros(2nq, 2nq), zeros(2nq, nu), collect(1:nq), collect(nq .+ (1:nq)))
-    finalizer(x -> ccall((:od_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), m)
-    return m
+    check(ccall((:od_create, LIB), Cint, (Cint, Cint, Ref{ODOptions}, Cdouble, Ref{Ptr{Cvoid}}), id, 0, o, Float64(h), hd))
+    # n, m default to 2nq, nu (:54); nc / nb only size the reference's contact-force buffers (:36-46, :58-59):
+    # no_impact => nc = 0, no_friction => nb = 0.  They are kept for callers that read them back.
+    nc_ = no_impact ? 0 : (nc === nothing ? (hasproperty(model, :nc) ? model.nc : 0) : nc)
+    nb_ = no_friction ? 0 : (nb === nothing ? 0 : nb)
+    im = ImplicitDynamics(hd[], model, nq, nu, n === nothing ? 2nq : n, m === nothing ? nu : m, d, nc_, nb_,
+                          zeros(2nq, 2nq), zeros(2nq, nu),
+                          collect(1:nq), collect(nq .+ (1:nq)), collect(2nq .+ (1:nu)), info)
+    if hasproperty(model, :friction) && length(model.friction) > 0     # friction_coefficients(model), cartpole/simulator_friction.jl:1
+        set_friction!(im, Float64.(collect(model.friction)))
+    end
+    finalizer(x -> ccall((:od_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), im)
+    return im
 end
 
-set_friction!(m::ImplicitDynamicsMI355X, μ::Vector{Float64}) =
-    check(ccall((:od_set_friction, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint), m.h, μ, length(μ)))
+set_friction!(im::ImplicitDynamics, μ::Vector{Float64}) =
+    check(ccall((:od_set_friction, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Cint), im.h, μ, length(μ)))
 
-"f(d, model, x, u, w) — src/dynamics.jl:81-94"
-function f(d, m::ImplicitDynamicsMI355X, x, u, w)
-    check(ccall((:od_f_host, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), m.h, x, u, d))
+# the reference mutates model.friction after construction (examples/cartpole.jl:21): re-read it on every call
+function sync_friction!(im::ImplicitDynamics)
+    if hasproperty(im.model, :friction) && length(im.model.friction) > 0
+        set_friction!(im, Float64.(collect(im.model.friction)))
+    end
+end
+
+"f(d, model, x, u, w) -- src/dynamics.jl:81-94"
+function f(d, im::ImplicitDynamics, x, u, w)
+    sync_friction!(im)
+    check(ccall((:od_f_host, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), im.h, x, u, d))
     return d
 end
 
-"fx(dx, model, x, u, w) — src/dynamics.jl:96-114 (writes the same three blocks as the reference)"
-function fx(dx, m::ImplicitDynamicsMI355X, x, u, w)
-    check(ccall((:od_fx_host, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), m.h, x, u, m.dx_buf))
-    for i = 1:m.nq
-        dx[m.idx_q1[i], m.idx_q2[i]] = 1.0
+function write_fx!(dx, im::ImplicitDynamics)      # the three blocks the reference writes (:105-111)
+    for i = 1:im.nq
+        dx[im.idx_q1[i], im.idx_q2[i]] = 1.0
     end
-    dx[m.idx_q2, m.idx_q1] .= @view m.dx_buf[m.idx_q2, m.idx_q1]
-    dx[m.idx_q2, m.idx_q2] .= @view m.dx_buf[m.idx_q2, m.idx_q2]
+    dx[im.idx_q2, im.idx_q1] .= @view im.dx_buf[im.idx_q2, im.idx_q1]
+    dx[im.idx_q2, im.idx_q2] .= @view im.dx_buf[im.idx_q2, im.idx_q2]
     return dx
 end
 
-"fu(du, model, x, u, w) — src/dynamics.jl:116-128"
-function fu(du, m::ImplicitDynamicsMI355X, x, u, w)
-    check(ccall((:od_fu_host, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), m.h, x, u, m.du_buf))
-    du[m.idx_q2, :] .= @view m.du_buf[m.idx_q2, :]
+"fx(dx, model, x, u, w) -- src/dynamics.jl:96-114"
+function fx(dx, im::ImplicitDynamics, x, u, w)
+    sync_friction!(im)
+    check(ccall((:od_fx_host, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), im.h, x, u, im.dx_buf))
+    return write_fx!(dx, im)
+end
+
+"fu(du, model, x, u, w) -- src/dynamics.jl:116-128"
+function fu(du, im::ImplicitDynamics, x, u, w)
+    sync_friction!(im)
+    check(ccall((:od_fu_host, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), im.h, x, u, im.du_buf))
+    du[im.idx_q2, :] .= @view im.du_buf[im.idx_q2, :]
     return du
 end
 
-"state_to_configuration — src/dynamics.jl:131-145"
+"f, fx and fu of one knot from one solve (the three reference callbacks solve three times)"
+function ffxfu!(d, dx, du, im::ImplicitDynamics, x, u, w)
+    sync_friction!(im)
+    check(ccall((:od_ffxfu_host, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                im.h, x, u, d, im.dx_buf, im.du_buf))
+    write_fx!(dx, im)
+    du[im.idx_q2, :] .= @view im.du_buf[im.idx_q2, :]
+    return d, dx, du
+end
+
+"state_to_configuration -- src/dynamics.jl:131-145"
 function state_to_configuration(x::Vector{Vector{T}}) where T
     nq = length(x[1]) ÷ 2
     q = Vector{T}[]
@@ -82,24 +152,123 @@ function state_to_configuration(x::Vector{Vector{T}}) where T
     return q
 end
 
-# batched entry points on device arrays (e.g. AMDGPU.ROCArray): Julia n×B matrices = OD_LAYOUT_BATCH_MAJOR
-function od_step_grad!(m::ImplicitDynamicsMI355X, B, X, U, D, DX, DU)
-    check(ccall((:od_set_layout, LIB), Cint, (Ptr{Cvoid}, Cint), m.h, 1))
+# ---- gradient bundle (src/gradient_bundle.jl) -------------------------------------------------------------------
+struct GradientBundle
+    N::Int
+    η::Matrix{Float64}          # (2nq+nu) x N: gb.ls.η, one nonzero per column (:49-54)
+    dz::Matrix{Float64}         # ny x nz (:102)
+    ny::Int; nz::Int
+end
+
+"GradientBundle(model; N, ϵ) -- src/gradient_bundle.jl:26-85 (sizes from the model, not from module globals)"
+function GradientBundle(model; N=100, ϵ=1.0e-4)
+    nq, nu = model.nq, model.nu
+    nz = 2nq + nu
+    η = zeros(nz, N)
+    for i = 1:N
+        η[rand(1:nz), i] = ϵ * randn()
+    end
+    GradientBundle(N, η, zeros(nq, nz), nq, nz)
+end
+
+"gradient!(sim, gb, q1, q2, u1) -- :87-104, on the handle's eval simulator"
+function gradient!(im::ImplicitDynamics, gb::GradientBundle, q1, q2, u1)
+    sync_friction!(im)
+    x = vcat(q1, q2)
+    check(ccall((:od_bundle_grad_host, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}),
+                im.h, gb.N, x, Float64.(collect(u1)), gb.η, gb.dz, C_NULL))
+    return gb.dz
+end
+
+"fx_gb(dx, model, x, u, w) -- :109-126 (model.info::GradientBundle)"
+function fx_gb(dx, im::ImplicitDynamics, x, u, w)
+    nq = im.nq
+    q1 = x[im.idx_q1]; q2 = x[im.idx_q2]
+    for i = 1:nq
+        dx[im.idx_q1[i], im.idx_q2[i]] = 1.0
+    end
+    gradient!(im, im.info, q1, q2, u)
+    dx[im.idx_q2, im.idx_q1] .= @view im.info.dz[:, im.idx_q1]
+    dx[im.idx_q2, im.idx_q2] .= @view im.info.dz[:, im.idx_q2]
+    return dx
+end
+
+"fu_gb(du, model, x, u, w) -- :136-147"
+function fu_gb(du, im::ImplicitDynamics, x, u, w)
+    q1 = x[im.idx_q1]; q2 = x[im.idx_q2]
+    gradient!(im, im.info, q1, q2, u)
+    du[im.idx_q2, :] .= @view im.info.dz[:, im.idx_u1]
+    return du
+end
+
+# ---- rocket (src/models/rocket/dynamics.jl): one OD_ROCKET_DYNAMICS handle plays ip_dyn and ip_proj -------------
+mutable struct RocketInfo
+    h::Ptr{Cvoid}
+    u_max::Float64; dt::Float64
+    up::Vector{Float64}; dp::Matrix{Float64}
+end
+
+"RocketInfo(rocket, u_max, h, r, rz, rθ, r_proj, rz_proj, rθ_proj) -- dynamics.jl:12-99 (the residual functions are ignored)"
+function RocketInfo(rocket, u_max, h, funcs...)
+    hd = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:od_create, LIB), Cint, (Cint, Cint, Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}), MODEL_IDS[:rocket], 0, C_NULL, Float64(h), hd))
+    check(ccall((:od_set_u_max, LIB), Cint, (Ptr{Cvoid}, Cdouble), hd[], Float64(u_max)))
+    r = RocketInfo(hd[], u_max, h, zeros(3), zeros(3, 3))
+    finalizer(x -> ccall((:od_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), r)
+    return r
+end
+
+rocket_host(info::RocketInfo, project, x, u, y, dx, du) =
+    check(ccall((:od_rocket_host, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}),
+                info.h, project, x, u, y, dx, du, C_NULL, C_NULL))
+
+"f_rocket(d, info, x, u, w) -- :101-114"
+f_rocket(d, info::RocketInfo, x, u, w) = (rocket_host(info, 0, x, u, d, C_NULL, C_NULL); d)
+"fx_rocket(dx, info, x, u, w) -- :134-147"
+fx_rocket(dx, info::RocketInfo, x, u, w) = (rocket_host(info, 0, x, u, C_NULL, dx, C_NULL); dx)
+"fu_rocket(du, info, x, u, w) -- :149-163"
+fu_rocket(du, info::RocketInfo, x, u, w) = (rocket_host(info, 0, x, u, C_NULL, C_NULL, du); du)
+"f_rocket_proj / fx_rocket_proj / fu_rocket_proj -- :215-268"
+f_rocket_proj(d, info::RocketInfo, x, u, w) = (rocket_host(info, 1, x, u, d, C_NULL, C_NULL); d)
+fx_rocket_proj(dx, info::RocketInfo, x, u, w) = (rocket_host(info, 1, x, u, C_NULL, dx, C_NULL); dx)
+fu_rocket_proj(du, info::RocketInfo, x, u, w) = (rocket_host(info, 1, x, u, C_NULL, C_NULL, du); du)
+
+"soc_projection(x, info) -- :168-186 (returns a vector owned by info, like the reference's view)"
+function soc_projection(x, info::RocketInfo)
+    check(ccall((:od_soc_project_host, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}), info.h, x, info.up, C_NULL, C_NULL))
+    return info.up
+end
+"soc_projection_gradient(x, info) -- :190-210"
+function soc_projection_gradient(x, info::RocketInfo)
+    check(ccall((:od_soc_project_host, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cint}), info.h, x, info.up, info.dp, C_NULL))
+    return info.dp
+end
+
+# ---- batched entry points on device arrays (e.g. AMDGPU.ROCArray): Julia n x B matrices = OD_LAYOUT_BATCH_MAJOR ----
+function od_step_grad!(im::ImplicitDynamics, B, X, U, D, DX, DU)
+    check(ccall((:od_set_layout, LIB), Cint, (Ptr{Cvoid}, Cint), im.h, 1))
     check(ccall((:od_step_grad, LIB), Cint, (Ptr{Cvoid}, Clong, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}),
-                m.h, B, pointer(X), pointer(U), pointer(D), pointer(DX), pointer(DU), C_NULL, C_NULL))
+                im.h, B, pointer(X), pointer(U), pointer(D), pointer(DX), pointer(DU), C_NULL, C_NULL))
 end
 
-function od_rollout!(m::ImplicitDynamicsMI355X, B, T, x1, U, X, A, Bm)
-    check(ccall((:od_set_layout, LIB), Cint, (Ptr{Cvoid}, Cint), m.h, 1))
+function od_rollout!(im::ImplicitDynamics, B, T, x1, U, X, A, Bm)
+    check(ccall((:od_set_layout, LIB), Cint, (Ptr{Cvoid}, Cint), im.h, 1))
     check(ccall((:od_rollout, LIB), Cint, (Ptr{Cvoid}, Clong, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}),
-                m.h, B, T, pointer(x1), pointer(U), pointer(X), pointer(A), pointer(Bm), C_NULL, C_NULL))
+                im.h, B, T, pointer(x1), pointer(U), pointer(X), pointer(A), pointer(Bm), C_NULL, C_NULL))
 end
 
-"whole solution on device arrays (contact impulses and their sensitivities): Z nz×B, DZ (nz*(2nq+nu))×B; rows via model_indices"
-function od_step_full!(m::ImplicitDynamicsMI355X, B, X, U, Z, DZ)
-    check(ccall((:od_set_layout, LIB), Cint, (Ptr{Cvoid}, Cint), m.h, 1))
+"rollout with the compact linearisation: G (nq*(2nq+nu)) x (T*B) = dq3/d(q1, q2, u1) per knot"
+function od_rollout_compact!(im::ImplicitDynamics, B, T, x1, U, X, G)
+    check(ccall((:od_set_layout, LIB), Cint, (Ptr{Cvoid}, Cint), im.h, 1))
+    check(ccall((:od_rollout_compact, LIB), Cint, (Ptr{Cvoid}, Clong, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}),
+                im.h, B, T, pointer(x1), pointer(U), pointer(X), pointer(G), C_NULL, C_NULL))
+end
+
+"whole solution on device arrays (contact impulses and their sensitivities): Z nz x B, DZ (nz*(2nq+nu)) x B; rows via model_indices"
+function od_step_full!(im::ImplicitDynamics, B, X, U, Z, DZ)
+    check(ccall((:od_set_layout, LIB), Cint, (Ptr{Cvoid}, Cint), im.h, 1))
     check(ccall((:od_step_full, LIB), Cint, (Ptr{Cvoid}, Clong, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}),
-                m.h, B, pointer(X), pointer(U), pointer(Z), pointer(DZ), C_NULL, C_NULL))
+                im.h, B, pointer(X), pointer(U), pointer(Z), pointer(DZ), C_NULL, C_NULL))
 end
 "1-based z indices of (:q | :γ | :b) for a model"
 function model_indices(model::Symbol, which::Symbol)
@@ -108,26 +277,14 @@ function model_indices(model::Symbol, which::Symbol)
     return Int.(buf[1:n]) .+ 1
 end
 
-# rocket (src/models/rocket/dynamics.jl): one OD_ROCKET_DYNAMICS handle plays ip_dyn and ip_proj
-mutable struct RocketInfoMI355X
-    h::Ptr{Cvoid}
-end
-function RocketInfoMI355X(u_max::Float64, h::Float64)
-    hd = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:od_create, LIB), Cint, (Cint, Cint, Ptr{Cvoid}, Cdouble, Ref{Ptr{Cvoid}}), MODEL_IDS[:rocket], 0, C_NULL, h, hd))
-    check(ccall((:od_set_u_max, LIB), Cint, (Ptr{Cvoid}, Cdouble), hd[], u_max))
-    r = RocketInfoMI355X(hd[])
-    finalizer(x -> ccall((:od_destroy, LIB), Cint, (Ptr{Cvoid},), x.h), r)
-    return r
-end
-"batched soc_projection / soc_projection_gradient (dynamics.jl:168-214) on device arrays: U 3×B, UP 3×B, DP 9×B"
-function od_soc_project!(r::RocketInfoMI355X, B, U, UP, DP)
+"batched soc_projection / soc_projection_gradient on device arrays: U 3 x B, UP 3 x B, DP 9 x B"
+function od_soc_project!(r::RocketInfo, B, U, UP, DP)
     check(ccall((:od_set_layout, LIB), Cint, (Ptr{Cvoid}, Cint), r.h, 1))
     check(ccall((:od_soc_project, LIB), Cint, (Ptr{Cvoid}, Clong, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}),
                 r.h, B, pointer(U), pointer(UP), pointer(DP), C_NULL))
 end
-"batched f_rocket(_proj) + fx + fu (dynamics.jl:101-164, 215-268): X 12×B, U 3×B -> Y 12×B, DX 144×B, DU 36×B"
-function od_rocket!(r::RocketInfoMI355X, B, project::Bool, X, U, Y, DX, DU)
+"batched f_rocket(_proj) + fx + fu: X 12 x B, U 3 x B -> Y 12 x B, DX 144 x B, DU 36 x B"
+function od_rocket!(r::RocketInfo, B, project::Bool, X, U, Y, DX, DU)
     check(ccall((:od_set_layout, LIB), Cint, (Ptr{Cvoid}, Cint), r.h, 1))
     check(ccall((:od_rocket, LIB), Cint, (Ptr{Cvoid}, Clong, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}),
                 r.h, B, project ? 1 : 0, pointer(X), pointer(U), pointer(Y), pointer(DX), pointer(DU), C_NULL, C_NULL))

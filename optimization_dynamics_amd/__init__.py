@@ -6,7 +6,7 @@ for gfx950 behind a C ABI (include/od_mi355x.h), with this package mirroring the
 Julia API (same names, argument meaning, in-place semantics).
 """
 from ._lib import Library, ODError, Options, default_library  # noqa: F401
-from .dynamics import ImplicitDynamics, f, fu, fx, state_to_configuration  # noqa: F401
+from .dynamics import ImplicitDynamics, f, ffxfu, fu, fx, state_to_configuration  # noqa: F401
 from .gradient_bundle import GradientBundle, MInfo, f_gb, fu_gb, fx_gb, gradient_, gradient_batch  # noqa: F401
 from .ilqr import ILQR, QuadraticObjective  # noqa: F401
 from .interior_point import InteriorPoint  # noqa: F401

@@ -75,6 +75,10 @@ SIGNATURES = {
     "od_f_host": (C.c_int, [_VP, _VP, _VP, _VP]),
     "od_fx_host": (C.c_int, [_VP, _VP, _VP, _VP]),
     "od_fu_host": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "od_ffxfu_host": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    "od_rocket_host": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _IP]),
+    "od_soc_project_host": (C.c_int, [_VP, _VP, _VP, _VP, _IP]),
+    "od_bundle_grad_host": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, _VP, _IP]),
 }
 
 

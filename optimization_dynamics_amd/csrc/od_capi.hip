@@ -1018,5 +1018,78 @@ static int host_call(od_handle h, const double* x, const double* u, double* d, d
 int od_f_host(od_handle h, const double* x, const double* u, double* d) { return host_call(h, x, u, d, nullptr, nullptr); }
 int od_fx_host(od_handle h, const double* x, const double* u, double* dx) { return host_call(h, x, u, nullptr, dx, nullptr); }
 int od_fu_host(od_handle h, const double* x, const double* u, double* du) { return host_call(h, x, u, nullptr, nullptr, du); }
+// f, fx and fu of one knot from ONE solve (the reference makes three, src/dynamics.jl:88,103,123); any output may be NULL
+int od_ffxfu_host(od_handle h, const double* x, const double* u, double* d, double* dx, double* du) {
+  return host_call(h, x, u, d, dx, du);
+}
+
+// device staging for host-pointer calls: `elems` doubles, grown on demand
+static int ensure_stage(od_handle_s* h, size_t elems) {
+  if (h->stage_elems >= elems) return OD_OK;
+  if (h->stage) {
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(OD_ERR_HIP, "hipStreamSynchronize failed");
+    (void)hipFree(h->stage);
+    h->stage = nullptr;
+    h->stage_elems = 0;
+  }
+  OD_HIP(hipMalloc((void**)&h->stage, elems * sizeof(double)));
+  h->stage_elems = elems;
+  return OD_OK;
+}
+
+// f_rocket / fx_rocket / fu_rocket (project = 0) and the *_proj variants (project = 1) for one (x, u) on host vectors
+// (src/models/rocket/dynamics.jl:101-164, 215-268); y 12, dx 12 x 12, du 12 x 3, uproj 3 (col-major); outputs may be NULL
+int od_rocket_host(od_handle h, int project, const double* x, const double* u, double* y, double* dx, double* du, double* uproj, int* status) {
+  if (!h || !x || !u) return fail(OD_ERR_INVALID, "od_rocket_host: null argument");
+  if (int rc = ensure_stage(h, 12 + 3 + 12 + 144 + 36 + 3 + 1)) return rc;
+  double* px = h->stage; double* pu = px + 12; double* py = pu + 3; double* pdx = py + 12; double* pdu = pdx + 144; double* pup = pdu + 36;
+  int* pst = (int*)(pup + 3);
+  OD_HIP(hipMemcpyAsync(px, x, 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  OD_HIP(hipMemcpyAsync(pu, u, 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (int rc = od_rocket(h, 1, project, px, pu, py, dx ? pdx : nullptr, du ? pdu : nullptr, pup, pst)) return rc;
+  if (y) OD_HIP(hipMemcpyAsync(y, py, 12 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (dx) OD_HIP(hipMemcpyAsync(dx, pdx, 144 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (du) OD_HIP(hipMemcpyAsync(du, pdu, 36 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (uproj && project) OD_HIP(hipMemcpyAsync(uproj, pup, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (status) OD_HIP(hipMemcpyAsync(status, pst, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  OD_HIP(hipStreamSynchronize(h->stream));
+  return OD_OK;
+}
+
+// soc_projection (duproj = NULL) / soc_projection_gradient for one u on host vectors (dynamics.jl:168-214)
+int od_soc_project_host(od_handle h, const double* u, double* uproj, double* duproj, int* status) {
+  if (!h || !u) return fail(OD_ERR_INVALID, "od_soc_project_host: null argument");
+  if (int rc = ensure_stage(h, 3 + 3 + 9 + 1)) return rc;
+  double* pu = h->stage; double* pup = pu + 3; double* pd = pup + 3;
+  int* pst = (int*)(pd + 9);
+  OD_HIP(hipMemcpyAsync(pu, u, 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (int rc = od_soc_project(h, 1, pu, pup, duproj ? pd : nullptr, pst)) return rc;
+  if (uproj) OD_HIP(hipMemcpyAsync(uproj, pup, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (duproj) OD_HIP(hipMemcpyAsync(duproj, pd, 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (status) OD_HIP(hipMemcpyAsync(status, pst, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  OD_HIP(hipStreamSynchronize(h->stream));
+  return OD_OK;
+}
+
+// gradient!(sim, gb, q1, q2, u1) for one knot on host vectors (src/gradient_bundle.jl:87-104): x = [q1; q2], eta
+// (2nq+nu) x N col-major, dz nq x (2nq+nu) col-major.  status: 1 = every sample converged and the fit is determined
+int od_bundle_grad_host(od_handle h, int N, const double* x, const double* u, const double* eta, double* dz, int* status) {
+  if (int rc = check_mech(h, "od_bundle_grad_host")) return rc;
+  if (!x || !eta || !dz || N <= 0 || (h->vt->nu > 0 && !u)) return fail(OD_ERR_INVALID, "od_bundle_grad_host: null argument");
+  const int nq = h->vt->nq, n = 2 * nq, nu = h->vt->nu, nzb = n + nu;
+  const size_t ws = (od_bundle_workspace_bytes(h, 1, N) + 7) / 8;
+  if (int rc = ensure_stage(h, (size_t)n + nu + (size_t)nzb * N + (size_t)nq * nzb + 1 + ws)) return rc;
+  double* px = h->stage; double* pu = px + n; double* pe = pu + nu; double* pdz = pe + (size_t)nzb * N;
+  int* pst = (int*)(pdz + (size_t)nq * nzb);
+  double* pws = pdz + (size_t)nq * nzb + 1;
+  OD_HIP(hipMemcpyAsync(px, x, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (nu) OD_HIP(hipMemcpyAsync(pu, u, nu * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  OD_HIP(hipMemcpyAsync(pe, eta, (size_t)nzb * N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (int rc = od_bundle_grad(h, 1, N, px, pu, pe, pdz, pws, ws * 8, pst)) return rc;
+  OD_HIP(hipMemcpyAsync(dz, pdz, (size_t)nq * nzb * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (status) OD_HIP(hipMemcpyAsync(status, pst, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  OD_HIP(hipStreamSynchronize(h->stream));
+  return OD_OK;
+}
 
 }  // extern "C"

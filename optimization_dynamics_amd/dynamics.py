@@ -264,6 +264,27 @@ def fu(du, model: ImplicitDynamics, x, u, w=None):
     return du
 
 
+def ffxfu(d, dx, du, model: ImplicitDynamics, x, u, w=None):
+    """f, fx and fu of one knot from ONE solve (od_ffxfu_host; the three reference callbacks solve three times):
+    writes d, the three blocks of dx and the lower block of du like f / fx / fu above"""
+    model._sync_friction()
+    nq, nu = model.model.nq, model.model.nu
+    n = 2 * nq
+    x = np.ascontiguousarray(x, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64)
+    if model.device.type == "cuda":
+        model.set_stream(None)
+    bd = np.zeros(n); bx = np.zeros(n * n); bu = np.zeros(n * nu)
+    model.lib.check(model.lib.cdll.od_ffxfu_host(model._h, x.ctypes.data, u.ctypes.data, bd.ctypes.data, bx.ctypes.data, bu.ctypes.data))
+    d[...] = bd.reshape(d.shape)
+    bx = bx.reshape(n, n, order="F"); bu = bu.reshape(n, nu, order="F")
+    for i in range(nq):
+        dx[model.idx_q1[i], model.idx_q2[i]] = 1.0
+    dx[np.ix_(model.idx_q2, model.idx_q1)] = bx[nq:, :nq]
+    dx[np.ix_(model.idx_q2, model.idx_q2)] = bx[nq:, nq:]
+    du[model.idx_q2, :] = bu[nq:, :]
+    return d, dx, du
+
+
 def state_to_configuration(x):
     """src/dynamics.jl:131-145: [x_1 .. x_H] (each [q_t; q_{t+1}]) -> [q_1, q_2, ..., q_{H+1}]."""
     q = []

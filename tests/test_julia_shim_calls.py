@@ -1,0 +1,107 @@
+"""The call sequences of julia/OptimizationDynamicsMI355X.jl, replayed through ctypes (Julia is absent here): every
+function of the shim is one or two ccalls on host vectors; this file makes exactly those calls, with the same argument
+order, NULLs and buffer shapes, against the host-emulation build (CPU tier) and checks the results against the batched
+entry points / the oracle.  A wrong argument order or a missing symbol in the shim's ccalls shows up here."""
+import ctypes as C
+import re
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import parity_checks as P
+import workloads as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _p(a):
+    return a.ctypes.data if a is not None else None
+
+
+def test_every_ccall_of_the_shim_names_an_exported_symbol_with_matching_arity(emu_lib):
+    from optimization_dynamics_amd import _lib
+    src = open(os.path.join(ROOT, "julia", "OptimizationDynamicsMI355X.jl")).read()
+    calls = re.findall(r"ccall\(\(:(\w+), LIB\), (\w+), \(([^)]*)\)", src)
+    assert len(calls) >= 20
+    for sym, ret, args in calls:
+        assert hasattr(emu_lib.cdll, sym), sym
+        if sym in _lib.SIGNATURES:
+            nargs = len([a for a in args.split(",") if a.strip()])
+            assert nargs == len(_lib.SIGNATURES[sym][1]), (sym, nargs, len(_lib.SIGNATURES[sym][1]))
+
+
+def test_implicit_dynamics_callbacks_sequence(oracle, emu_lib):
+    """f / fx / fu / ffxfu! (od_f_host, od_fx_host, od_fu_host, od_ffxfu_host) incl. the friction re-sync before each"""
+    name = "cartpole_friction"
+    X, U = W.knots(name, 3, seed=51)
+    im = P.make_im(name, emu_lib, "cpu")
+    h = im._h
+    mu = np.array([0.35, 0.35])
+    n, nu = 4, 1
+    for b in range(3):
+        x, u = np.ascontiguousarray(X[:, b]), np.ascontiguousarray(U[:, b])
+        d = np.zeros(n); dxb = np.zeros((n, n), order="F"); dub = np.zeros((n, nu), order="F")
+        assert emu_lib.cdll.od_set_friction(h, mu.ctypes.data_as(C.POINTER(C.c_double)), 2) == 0
+        assert emu_lib.cdll.od_f_host(h, _p(x), _p(u), _p(d)) == 0
+        assert emu_lib.cdll.od_fx_host(h, _p(x), _p(u), _p(dxb)) == 0
+        assert emu_lib.cdll.od_fu_host(h, _p(x), _p(u), _p(dub)) == 0
+        d2 = np.zeros(n); dx2 = np.zeros((n, n), order="F"); du2 = np.zeros((n, nu), order="F")
+        assert emu_lib.cdll.od_ffxfu_host(h, _p(x), _p(u), _p(d2), _p(dx2), _p(du2)) == 0
+        assert np.array_equal(d, d2) and np.array_equal(dxb, dx2) and np.array_equal(dub, du2)
+        sim = P.make_sim(oracle, name)
+        so, do, _ = oracle.f(sim, x, u)
+        _, dxo, _ = oracle.fx(sim, x, u)
+        _, duo, _ = oracle.fu(sim, x, u)
+        assert np.abs(d - do).max() < 1e-6 and np.abs(dxb - dxo).max() < 1e-4 * max(1, np.abs(dxo).max()) and np.abs(dub - duo).max() < 1e-4 * max(1, np.abs(duo).max())
+    # partial outputs: NULLs as the shim passes them
+    d3 = np.zeros(n)
+    assert emu_lib.cdll.od_ffxfu_host(h, _p(x), _p(u), _p(d3), None, None) == 0 and np.array_equal(d3, d2)
+
+
+def test_gradient_bundle_sequence(oracle, emu_lib):
+    """gradient! / fx_gb / fu_gb: od_bundle_grad_host(h, N, x, u, eta, dz, NULL)"""
+    from optimization_dynamics_amd import gradient_bundle as gbm, models
+    name = "hopper"
+    X, U = W.knots(name, 2, seed=31)
+    gb = gbm.GradientBundle(models.BY_NAME[name], N=50, eps=1e-4, seed=5)
+    im = P.make_im(name, emu_lib, "cpu", info=gb)
+    nq, nzb = 4, 10
+    dzb, st = gbm.gradient_batch(im, gb, torch.tensor(X), torch.tensor(U))
+    for b in range(2):
+        x, u = np.ascontiguousarray(X[:, b]), np.ascontiguousarray(U[:, b])
+        dz = np.zeros((nq, nzb), order="F")
+        eta = np.asfortranarray(gb.eta)
+        assert emu_lib.cdll.od_bundle_grad_host(im._h, 50, _p(x), _p(u), _p(eta), _p(dz), None) == 0
+        assert np.array_equal(dz, dzb[:, :, b].numpy())
+
+
+def test_rocket_sequence(oracle, emu_lib):
+    """RocketInfo: od_create(rocket, NULL opts) + od_set_u_max; f/fx/fu_rocket(_proj) = od_rocket_host with NULLs;
+    soc_projection(_gradient) = od_soc_project_host"""
+    from optimization_dynamics_amd import models, rocket as rk
+    hd = C.c_void_p()
+    assert emu_lib.cdll.od_create(5, 0, None, C.c_double(0.05), C.byref(hd)) == 0
+    assert emu_lib.cdll.od_set_u_max(hd, C.c_double(12.5)) == 0
+    Xr, Ur = W.rocket_inputs(3, seed=1)
+    info = rk.RocketInfo(models.rocket, 12.5, 0.05, device="cpu", lib=emu_lib)
+    for project in (0, 1):
+        Yb, DXb, DUb, UPb, stb = info.solve(torch.tensor(Xr), torch.tensor(Ur), project=bool(project), grads=True)
+        for b in range(3):
+            x, u = np.ascontiguousarray(Xr[:, b]), np.ascontiguousarray(Ur[:, b])
+            y = np.zeros(12); dx = np.zeros((12, 12), order="F"); du = np.zeros((12, 3), order="F")
+            assert emu_lib.cdll.od_rocket_host(hd, project, _p(x), _p(u), _p(y), None, None, None, None) == 0       # f_rocket(_proj)
+            assert emu_lib.cdll.od_rocket_host(hd, project, _p(x), _p(u), None, _p(dx), None, None, None) == 0      # fx_rocket(_proj)
+            assert emu_lib.cdll.od_rocket_host(hd, project, _p(x), _p(u), None, None, _p(du), None, None) == 0      # fu_rocket(_proj)
+            assert np.array_equal(y, Yb[:, b].numpy()) and np.array_equal(dx, DXb[:, :, b].numpy()) and np.array_equal(du, DUb[:, :, b].numpy())
+    up = np.zeros(3); dp = np.zeros((3, 3), order="F")
+    u = np.ascontiguousarray(Ur[:, 0])
+    assert emu_lib.cdll.od_soc_project_host(hd, _p(u), _p(up), None, None) == 0
+    up2 = up.copy()
+    assert emu_lib.cdll.od_soc_project_host(hd, _p(u), _p(up), _p(dp), None) == 0
+    assert np.array_equal(up, up2)
+    s, z, dzo, it = oracle.soc_projection(12.5, u, True)
+    assert np.abs(up - z[:3]).max() < 2e-4 * max(1, np.abs(z[:3]).max())
+    assert np.hypot(up[0], up[1]) <= up[2] + 2e-2            # examples/rocket.jl:151
+    assert emu_lib.cdll.od_destroy(hd) == 0
