@@ -63,6 +63,11 @@ const char* od_last_error(void);
 /* model table: dimensions of src/models/<model> (nq, nu, nz = num_var, ntheta = num_data, nfric) */
 int od_model_dims(int model, int* nq, int* nu, int* nz, int* ntheta, int* nfric);
 const char* od_model_name(int model);
+/* models are addressed by id; ids 0..7 are the enum above, models added with the generator
+ * (python -m optimization_dynamics_amd.codegen --add spec.py, the counterpart of deps/build.jl:27-48) follow */
+int od_default_friction(int model, double* mu, int n);   /* friction_coefficients(model) of the generated model, n <= 4 */
+int od_num_models(void);
+int od_model_id(const char* name);   /* -1 if unknown */
 /* option preset of the example that uses the model (examples/<model>.jl) */
 int od_default_options(int model, od_options* out);
 

@@ -39,6 +39,9 @@ SIGNATURES = {
     "od_version": (C.c_int, []),
     "od_last_error": (C.c_char_p, []),
     "od_model_dims": (C.c_int, [C.c_int] + [C.POINTER(C.c_int)] * 5),
+    "od_default_friction": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.c_int]),
+    "od_num_models": (C.c_int, []),
+    "od_model_id": (C.c_int, [C.c_char_p]),
     "od_model_name": (C.c_char_p, [C.c_int]),
     "od_default_options": (C.c_int, [C.c_int, C.POINTER(Options)]),
     "od_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(Options), C.c_double, C.POINTER(_VP)]),
@@ -96,6 +99,13 @@ class Library:
             fn = getattr(self.cdll, name)   # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        # the library's own registry: the eight models of the reference plus whatever the generator added (--add)
+        self.model_ids = {self.cdll.od_model_name(i).decode(): i for i in range(self.cdll.od_num_models())}
+
+    def model_id(self, name):
+        if name not in self.model_ids:
+            raise ODError("model %r is not in this library (has: %s)" % (name, ", ".join(self.model_ids)))
+        return self.model_ids[name]
 
     def check(self, rc):
         if rc != 0:
@@ -103,7 +113,7 @@ class Library:
 
     def model_dims(self, model):
         v = [C.c_int() for _ in range(5)]
-        self.check(self.cdll.od_model_dims(MODEL_IDS[model], *[C.byref(x) for x in v]))
+        self.check(self.cdll.od_model_dims(self.model_id(model), *[C.byref(x) for x in v]))
         return dict(zip(["nq", "nu", "nz", "ntheta", "nfric"], [x.value for x in v]))
 
     def model_indices(self, model):
@@ -111,7 +121,7 @@ class Library:
         out = {}
         for key, which in (("q", 0), ("gamma", 1), ("b", 2)):
             buf = (C.c_int * 16)()
-            n = self.cdll.od_model_indices(MODEL_IDS[model], which, buf, 16)
+            n = self.cdll.od_model_indices(self.model_id(model), which, buf, 16)
             if n < 0:
                 self.check(n)
             out[key] = [buf[i] for i in range(n)]
@@ -119,12 +129,12 @@ class Library:
 
     def raw_grad_dims(self, model):
         a, b = C.c_int(), C.c_int()
-        self.check(self.cdll.od_raw_grad_dims(MODEL_IDS[model], C.byref(a), C.byref(b)))
+        self.check(self.cdll.od_raw_grad_dims(self.model_id(model), C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def default_options(self, model):
         o = Options()
-        self.check(self.cdll.od_default_options(MODEL_IDS[model], C.byref(o)))
+        self.check(self.cdll.od_default_options(self.model_id(model), C.byref(o)))
         return o
 
 

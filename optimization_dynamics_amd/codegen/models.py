@@ -12,6 +12,8 @@ UNVERIFIED ("parity unpinned").
 """
 from __future__ import annotations
 
+import json
+import os
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -552,3 +554,62 @@ ALL_MODELS: Dict[str, Callable[[], ModelSpec]] = {
     "rocket_projection": rocket_projection,
     "hopper": hopper,
 }
+
+
+# ---------------------------------------------------------------------------------
+# user models (python -m optimization_dynamics_amd.codegen --add spec.py)
+# ---------------------------------------------------------------------------------
+def _load_spec_module(path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("od_user_spec_" + os.path.splitext(os.path.basename(path))[0], path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not hasattr(mod, "spec"):
+        raise ValueError("%s does not define spec() -> ModelSpec" % path)
+    return mod
+
+
+def _registry(udir):
+    p = os.path.join(udir, "registry.json")
+    return json.load(open(p)) if os.path.exists(p) else {"models": []}
+
+
+def register_user_model(path, udir):
+    """copy the spec file into the package and give its model the next free id; returns the model name"""
+    import shutil
+    mod = _load_spec_module(path)
+    m = mod.spec()
+    if not isinstance(m, ModelSpec):
+        raise ValueError("spec() of %s does not return a ModelSpec" % path)
+    if m.name in ALL_MODELS:
+        raise ValueError("model name %r is one of the built-in models" % m.name)
+    if m.kind != "mech":
+        raise ValueError("user models are mechanical models (theta = [q0; q1; u; friction; h])")
+    os.makedirs(udir, exist_ok=True)
+    reg = _registry(udir)
+    names = [e["name"] for e in reg["models"]]
+    if m.name not in names:
+        reg["models"].append({"name": m.name, "file": m.name + ".py"})
+    dst = os.path.join(udir, m.name + ".py")
+    if os.path.abspath(path) != os.path.abspath(dst):
+        shutil.copyfile(path, dst)
+    json.dump(reg, open(os.path.join(udir, "registry.json"), "w"), indent=1)
+    return m.name
+
+
+def user_model_id(name, udir):
+    names = [e["name"] for e in _registry(udir)["models"]]
+    return len(ALL_MODELS) + names.index(name)
+
+
+def all_models(udir=None) -> Dict[str, Callable[[], ModelSpec]]:
+    """built-in models plus the registered user models (ids continue after the built-in ones)"""
+    udir = udir or os.path.join(os.path.dirname(os.path.abspath(__file__)), "user_models")
+    out = dict(ALL_MODELS)
+    for k, e in enumerate(_registry(udir)["models"]):
+        def make(e=e, k=k):
+            m = _load_spec_module(os.path.join(udir, e["file"])).spec()
+            m.model_id = len(ALL_MODELS) + k
+            return m
+        out[e["name"]] = make
+    return out

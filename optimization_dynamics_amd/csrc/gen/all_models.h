@@ -1,4 +1,4 @@
-// GENERATED -- registry of device models
+// GENERATED -- every device model header
 #pragma once
 #include "acrobot_impact.h"
 #include "acrobot_nominal.h"
@@ -8,12 +8,3 @@
 #include "rocket_dynamics.h"
 #include "rocket_projection.h"
 #include "hopper.h"
-#define OD_FOR_EACH_MODEL(X) \
-  X(acrobot_impact) \
-  X(acrobot_nominal) \
-  X(cartpole_friction) \
-  X(cartpole_frictionless) \
-  X(planar_push) \
-  X(rocket_dynamics) \
-  X(rocket_projection) \
-  X(hopper)

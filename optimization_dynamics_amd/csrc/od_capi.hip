@@ -26,14 +26,9 @@ int fail(int code, const std::string& msg) {
 
 const ModelVT* vt_of(int model) {
   switch (model) {
-    case OD_ACROBOT_IMPACT: return vt_acrobot_impact();
-    case OD_ACROBOT_NOMINAL: return vt_acrobot_nominal();
-    case OD_CARTPOLE_FRICTION: return vt_cartpole_friction();
-    case OD_CARTPOLE_FRICTIONLESS: return vt_cartpole_frictionless();
-    case OD_PLANAR_PUSH: return vt_planar_push();
-    case OD_ROCKET_DYNAMICS: return vt_rocket_dynamics();
-    case OD_ROCKET_PROJECTION: return vt_rocket_projection();
-    case OD_HOPPER: return vt_hopper();
+#define OD_VT_CASE(name, id) case id: return vt_##name();
+    OD_FOR_EACH_MODEL(OD_VT_CASE)
+#undef OD_VT_CASE
     default: return nullptr;
   }
 }
@@ -588,6 +583,24 @@ int od_model_dims(int model, int* nq, int* nu, int* nz, int* ntheta, int* nfric)
   if (ntheta) *ntheta = vt->nth;
   if (nfric) *nfric = vt->nfric;
   return OD_OK;
+}
+
+int od_default_friction(int model, double* mu, int n) {
+  const ModelVT* vt = vt_of(model);
+  if (!vt || !mu) return fail(OD_ERR_INVALID, "od_default_friction: bad arguments");
+  for (int i = 0; i < n && i < 4; ++i) mu[i] = vt->fric_default[i];
+  return OD_OK;
+}
+
+int od_num_models(void) { return OD_MODEL_COUNT; }
+
+int od_model_id(const char* name) {
+  if (!name) return -1;
+  for (int i = 0; i < OD_MODEL_COUNT; ++i) {
+    const ModelVT* vt = vt_of(i);
+    if (vt && std::strcmp(vt->name, name) == 0) return i;
+  }
+  return -1;
 }
 
 const char* od_model_name(int model) {

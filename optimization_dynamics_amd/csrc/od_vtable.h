@@ -36,14 +36,12 @@ template <int N> constexpr std::array<int, 12> od_pad12(const int (&a)[N], int n
   return r;
 }
 
-const ModelVT* vt_acrobot_impact();
-const ModelVT* vt_acrobot_nominal();
-const ModelVT* vt_cartpole_friction();
-const ModelVT* vt_cartpole_frictionless();
-const ModelVT* vt_planar_push();
-const ModelVT* vt_rocket_dynamics();
-const ModelVT* vt_rocket_projection();
-const ModelVT* vt_hopper();
+// one launch table per model of the generated registry (gen/model_list.h, written by the generator: the eight models
+// of the reference plus whatever `python -m optimization_dynamics_amd.codegen --add spec.py` registered)
+#include "gen/model_list.h"
+#define OD_DECLARE_VT(name, id) const ModelVT* vt_##name();
+OD_FOR_EACH_MODEL(OD_DECLARE_VT)
+#undef OD_DECLARE_VT
 
 hipError_t launch_rocket64(const RocketArgs<double>&, int ppw, hipStream_t);
 hipError_t launch_rocket32(const RocketArgs<float>&, int ppw, hipStream_t);

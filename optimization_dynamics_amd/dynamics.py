@@ -55,7 +55,7 @@ class ImplicitDynamics:
                 setattr(o, k, v)
         self.options = o
         hd = C.c_void_p()
-        self.lib.check(self.lib.cdll.od_create(_lib.MODEL_IDS[model.name], _lib.OD_F64, C.byref(o), self.h, C.byref(hd)))
+        self.lib.check(self.lib.cdll.od_create(self.lib.model_id(model.name), _lib.OD_F64, C.byref(o), self.h, C.byref(hd)))
         self._h = hd
         self._fric_sent = None
         self._sync_friction()

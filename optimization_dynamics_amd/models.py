@@ -3,6 +3,8 @@
 `RoboDojo.hopper`, examples/hopper.jl:14).  They carry only what the host API needs: dimensions and
 the mutable friction vector (`cartpole_friction.friction .= [0.35; 0.35]`, examples/cartpole.jl:21);
 the residual math itself lives in the generated device code (csrc/gen)."""
+import ctypes as C
+
 import numpy as np
 
 
@@ -34,3 +36,17 @@ hopper = Model("hopper", 4, 2, 0, 4, friction=[0.5, 0.5], foot_radius=0.05, body
 
 BY_NAME = {m.name: m for m in [acrobot_impact, acrobot_nominal, cartpole_friction, cartpole_frictionless,
                                planarpush, rocket, hopper]}
+
+
+def from_library(lib, name):
+    """a Model for any model of the loaded library -- in particular one added with
+    `python -m optimization_dynamics_amd.codegen --add spec.py`; friction = the generated defaults"""
+    if name in BY_NAME:
+        return BY_NAME[name]
+    d = lib.model_dims(name)
+    ix = lib.model_indices(name)
+    fr = (C.c_double * 4)()
+    lib.check(lib.cdll.od_default_friction(lib.model_id(name), fr, 4))
+    m = Model(name, d["nq"], d["nu"], 0, len(ix["gamma"]), friction=[fr[i] for i in range(d["nfric"])])
+    BY_NAME[name] = m
+    return m

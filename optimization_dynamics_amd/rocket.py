@@ -37,7 +37,7 @@ class RocketInfo:
         self.options = o
         hd = C.c_void_p()
         od_dtype = _lib.OD_F64 if dtype == torch.float64 else _lib.OD_F32
-        self.lib.check(self.lib.cdll.od_create(_lib.MODEL_IDS["rocket_dynamics"], od_dtype, C.byref(o), self.h, C.byref(hd)))
+        self.lib.check(self.lib.cdll.od_create(self.lib.model_id("rocket_dynamics"), od_dtype, C.byref(o), self.h, C.byref(hd)))
         self._h = hd
         self.lib.check(self.lib.cdll.od_set_u_max(self._h, self.u_max))
 

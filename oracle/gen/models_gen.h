@@ -1,4 +1,4 @@
-/* GENERATED -- registry of oracle models */
+/* GENERATED -- registry of oracle models (index = model id) */
 #include "acrobot_impact.h"
 #include "acrobot_nominal.h"
 #include "cartpole_friction.h"

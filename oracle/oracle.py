@@ -42,6 +42,8 @@ def lib():
     if _LIB is None:
         _LIB = C.CDLL(build())
         _LIB.od_oracle_model_name.restype = C.c_char_p
+        for i in range(_LIB.od_oracle_num_models_()):          # the generated registry (incl. models added with --add)
+            MODEL_IDS[_LIB.od_oracle_model_name(i).decode()] = i
     return _LIB
 
 
