@@ -267,6 +267,9 @@ def _emit(m: ModelSpec, d: Derived) -> str:
     w("struct Coop_%s {\n" % n)
     w("  using M = Model_%s;\n" % n)
     w("  static constexpr int NQ = %d, NC = %d, NK = %d, SH = %d;\n" % (nq, NC, NK, SH))
+    w("  // chosen automatically for small batches only where the lanes have enough to share (measured: the hopper's 4 contacts\n")
+    w("  // + 2 cones halve the time of a rollout; the acrobot's 2 contacts do not pay for the replicated evaluation)\n")
+    w("  static constexpr bool AUTO = %s;\n" % ("true" if NC + NK >= 4 else "false"))
 
     def arr(name, xs, ty="int"):
         xs = list(xs) or [0]

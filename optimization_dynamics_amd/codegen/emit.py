@@ -390,8 +390,17 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
     o.write("#pragma once\n#include \"../od_math.h\"\n\nnamespace od {\n\n")
 
     const_entries = {(i, j): float(d.rz[i, j]) for (i, j) in d.rz_nz if d.rz[i, j].is_Number}
-    el = _Elim(m.nz, d.rz_nz, m.elim, set(m.floor_pivots), m.swaps,
-               set(m.idx_zq) if (m.soc and m.kind == 'mech') else (), const_entries)
+    tail_last = set(m.idx_zq) if (m.soc and m.kind == 'mech') else ()
+    el = _Elim(m.nz, d.rz_nz, m.elim, set(m.floor_pivots), m.swaps, tail_last, const_entries)
+    # the "state" program of the interior-point iterations (factor<false> / solve<false>): the same elimination continued
+    # through the cone leftovers (m.elim_state), so that only the configuration block is left as dense tail; without
+    # m.elim_state it is the first program with its tail taken down the diagonal (m.static_tail)
+    el_s = None
+    if m.elim_state:
+        el_s = _Elim(m.nz, d.rz_nz, m.elim_state, set(m.floor_pivots), m.swaps, tail_last, const_entries)
+    has_state = bool(el_s is not None or (m.static_tail and el.m > 0))
+    els = el_s if el_s is not None else el
+    state_tail_piv = bool(m.state_tail_pivot) if el_s is not None else False
     nnz = len(d.rz_nz)
     nnzth = len(d.rth_nz)
 
@@ -418,9 +427,11 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
     o.write("  static constexpr int NORT = %d, NSOC = %d, MAXSOC = %d, NEQ = %d, NBIL = %d, NZQ = %d;\n"
             % (len(m.ort[0]), len(m.soc), max_soc, len(m.equr), len(m.bil), len(m.idx_zq)))
     o.write("  static constexpr bool REG_POSTHOC = %s;\n" % ("true" if d.reg_posthoc else "false"))
-    o.write("  static constexpr int NFACT = %d, MTAIL = %d, TAIL_BASE = %d, NSWAP = %d;\n" % (el.slots, el.m, el.tail_base, len(el.swaps)))
-    o.write("  // the interior-point iterations may factor the tail without runtime pivoting (gradient solves always pivot)\n")
-    o.write("  static constexpr bool STATIC_TAIL = %s;\n" % ("true" if (m.static_tail and el.m > 0) else "false"))
+    o.write("  static constexpr int NFACT = %d, MTAIL = %d, TAIL_BASE = %d, NSWAP = %d;\n" % (max(el.slots, els.slots), el.m, el.tail_base, len(el.swaps)))
+    o.write("  // the interior-point iterations have their own elimination program, factor<false> / solve<false> (no runtime\n")
+    o.write("  // pivoting beyond the cone role swaps%s); gradient solves always use factor<true>\n" % (", pivoted %dx%d configuration tail" % (els.m, els.m) if state_tail_piv else ""))
+    o.write("  static constexpr bool STATIC_TAIL = %s;\n" % ("true" if has_state else "false"))
+    o.write("  static constexpr int MTAIL_S = %d, TAIL_BASE_S = %d;\n" % (els.m, els.tail_base))
     o.write(arr("ORT1", m.ort[0]) + arr("ORT2", m.ort[1]) + arr("ORTR", m.ortr))
     o.write(arr("SOCOFF", soc_off) + arr("SOC1", soc_flat_p) + arr("SOC2", soc_flat_d) + arr("SOCR", socr_flat))
     o.write(arr("EQUR", m.equr) + arr("BIL", m.bil) + arr("ZQ", m.idx_zq))
@@ -636,46 +647,55 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
 
     # ---- factor ----
     o.write("  template <class T> struct Fact { T v[NFACT > 0 ? NFACT : 1]; int piv[MTAIL > 0 ? MTAIL : 1]; bool sw[NSWAP > 0 ? NSWAP : 1]; };\n\n")
-    o.write("  // statically ordered sparse elimination (%d pivots) + %dx%d runtime-pivoted dense tail\n"
-            % (len(m.elim), el.m, el.m))
-    o.write("  template <bool PIV = true, class T, class F> OD_HD static bool factor(const T* a, F& f) {\n")
-    for k, (i, j) in enumerate(d.rz_nz):
-        o.write("    T a_%d_%d = a[%d];\n" % (i, j, k))
-    fills = sorted(el.final_pattern - set(d.rz_nz))
-    for (i, j) in fills:
-        if (i, j) in el.init_zero:
-            o.write("    T a_%d_%d = T(0);\n" % (i, j))
-        else:
-            o.write("    T a_%d_%d = T(0);\n" % (i, j))
-    for ln in el.swap_lines:
-        o.write("    " + ln + "\n")
-    for ln in el.fac_lines:
-        o.write("    " + ln + "\n")
-    if el.m > 0:
-        o.write("    T tl_[MTAIL * MTAIL];\n")
-    for ii, i in enumerate(el.tail_rows):
-        for jj, j in enumerate(el.tail_cols):
-            if (i, j) in el.final_const:
-                o.write("    tl_[%d] = %s;\n" % (ii + el.m * jj, _lit(el.final_const[(i, j)])))
-            elif (i, j) in el.final_pattern:
-                o.write("    tl_[%d] = a_%d_%d;\n" % (ii + el.m * jj, i, j))
+
+    def factor_body(e, mode, ind):
+        """mode: 'piv' runtime-pivoted tail | 'static' tail down the diagonal"""
+        w = lambda t: o.write(ind + t + "\n")
+        for k, (i, j) in enumerate(d.rz_nz):
+            w("T a_%d_%d = a[%d];" % (i, j, k))
+        for (i, j) in sorted(e.final_pattern - set(d.rz_nz)):
+            w("T a_%d_%d = T(0);" % (i, j))
+        for ln in e.swap_lines:
+            w(ln)
+        for ln in e.fac_lines:
+            w(ln)
+        if e.m > 0:
+            w("T tl_[%d];" % (e.m * e.m))
+        for ii, i in enumerate(e.tail_rows):
+            for jj, j in enumerate(e.tail_cols):
+                if (i, j) in e.final_const:
+                    w("tl_[%d] = %s;" % (ii + e.m * jj, _lit(e.final_const[(i, j)])))
+                elif (i, j) in e.final_pattern:
+                    w("tl_[%d] = a_%d_%d;" % (ii + e.m * jj, i, j))
+                else:
+                    w("tl_[%d] = T(0);" % (ii + e.m * jj))
+        if e.m > 0:
+            if mode == "piv":
+                w("const bool ok_ = od_lu_factor<T, %d>(tl_, f.piv);" % e.m)
             else:
-                o.write("    tl_[%d] = T(0);\n" % (ii + el.m * jj))
-    if el.m > 0:
-        o.write("    bool ok_;\n    if constexpr (PIV) ok_ = od_lu_factor<T, MTAIL>(tl_, f.piv);\n    else ok_ = od_lu_factor_static<T, MTAIL>(tl_);\n")
-        o.write("#pragma unroll\n    for (int i = 0; i < MTAIL * MTAIL; ++i) f.v[TAIL_BASE + i] = tl_[i];\n")
-        o.write("    return ok_;\n")
+                w("const bool ok_ = od_lu_factor_static<T, %d>(tl_);" % e.m)
+            o.write("#pragma unroll\n")
+            w("for (int i = 0; i < %d; ++i) f.v[%d + i] = tl_[i];" % (e.m * e.m, e.tail_base))
+            w("return ok_;")
+        else:
+            w("return true;")
+
+    o.write("  // factor<true>: statically ordered sparse elimination (%d pivots) + %dx%d runtime-pivoted dense tail\n" % (len(m.elim), el.m, el.m))
+    if has_state:
+        o.write("  // factor<false>: %d static pivots + %dx%d %s tail (interior-point iterations)\n"
+                % (len(els.order), els.m, els.m, "runtime-pivoted" if state_tail_piv else "unpivoted"))
+    o.write("  template <bool PIV = true, class T, class F> OD_HD static bool factor(const T* a, F& f) {\n")
+    if has_state:
+        o.write("    if constexpr (PIV) {\n")
+        factor_body(el, "piv", "      ")
+        o.write("    } else {\n")
+        factor_body(els, "piv" if state_tail_piv else "static", "      ")
+        o.write("    }\n")
     else:
-        o.write("    return true;\n")
+        factor_body(el, "piv", "    ")
     o.write("  }\n\n")
 
     # ---- solve ----
-    o.write("  // x = rz^{-1} b using the stored factors (b and x may alias)\n")
-    o.write("  template <bool PIV = true, class T, class F> OD_HD static void solve(const F& f, const T* b, T* x) {\n")
-    for i in range(m.nz):
-        o.write("    T y_%d = b[%d];\n" % (i, i))
-    for k, ((ra, rb), (ca, cb)) in enumerate(el.swaps):
-        o.write("    { const T u_ = y_%d, w_ = y_%d; y_%d = f.sw[%d] ? w_ : u_; y_%d = f.sw[%d] ? u_ : w_; }\n" % (ra, rb, ra, k, rb, k))
     def _mul(val, operand):
         """code for val * operand; val = ('c', float) | ('s', slot)"""
         if val[0] == "s":
@@ -687,31 +707,50 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
             return "-%s" % operand
         return "%s * %s" % (_lit(c), operand)
 
-    for (prw, fw) in el.fwd:
-        for (i, lval) in fw:
-            if lval[0] == "c" and lval[1] == 0.0:
-                continue
-            o.write("    y_%d -= %s;\n" % (i, _mul(lval, "y_%d" % prw)))
-    if el.m > 0:
-        o.write("    T t_[MTAIL];\n")
-        for ii, i in enumerate(el.tail_rows):
-            o.write("    t_[%d] = y_%d;\n" % (ii, i))
-        o.write("    if constexpr (PIV) od_lu_solve<T, MTAIL>(od_tail_view<T, TAIL_BASE>(f), f.piv, t_);\n")
-        o.write("    else od_lu_solve_static<T, MTAIL>(od_tail_view<T, TAIL_BASE>(f), t_);\n")
-        for jj, j in enumerate(el.tail_cols):
-            o.write("    const T x_%d = t_[%d];\n" % (j, jj))
-    for (prw, pc, ipval, us) in reversed(el.bwd):
-        terms = "".join(" - (%s)" % _mul(uv, "x_%d" % j) for (j, uv) in us if not (uv[0] == "c" and uv[1] == 0.0))
-        o.write("    const T x_%d = %s;\n" % (pc, _mul(ipval, "(y_%d%s)" % (prw, terms))))
-    swapped = {}
-    for k, ((ra, rb), (ca, cb)) in enumerate(el.swaps):
-        swapped[ca] = (cb, k)
-        swapped[cb] = (ca, k)
-    for j in range(m.nz):
-        if j in swapped:
-            o.write("    x[%d] = f.sw[%d] ? x_%d : x_%d;\n" % (j, swapped[j][1], swapped[j][0], j))
-        else:
-            o.write("    x[%d] = x_%d;\n" % (j, j))
+    def solve_body(e, mode, ind):
+        w = lambda t: o.write(ind + t + "\n")
+        for i in range(m.nz):
+            w("T y_%d = b[%d];" % (i, i))
+        for k, ((ra, rb), (ca, cb)) in enumerate(e.swaps):
+            w("{ const T u_ = y_%d, w_ = y_%d; y_%d = f.sw[%d] ? w_ : u_; y_%d = f.sw[%d] ? u_ : w_; }" % (ra, rb, ra, k, rb, k))
+        for (prw, fw) in e.fwd:
+            for (i, lval) in fw:
+                if lval[0] == "c" and lval[1] == 0.0:
+                    continue
+                w("y_%d -= %s;" % (i, _mul(lval, "y_%d" % prw)))
+        if e.m > 0:
+            w("T t_[%d];" % e.m)
+            for ii, i in enumerate(e.tail_rows):
+                w("t_[%d] = y_%d;" % (ii, i))
+            if mode == "piv":
+                w("od_lu_solve<T, %d>(od_tail_view<T, %d>(f), f.piv, t_);" % (e.m, e.tail_base))
+            else:
+                w("od_lu_solve_static<T, %d>(od_tail_view<T, %d>(f), t_);" % (e.m, e.tail_base))
+            for jj, j in enumerate(e.tail_cols):
+                w("const T x_%d = t_[%d];" % (j, jj))
+        for (prw, pc, ipval, us) in reversed(e.bwd):
+            terms = "".join(" - (%s)" % _mul(uv, "x_%d" % j) for (j, uv) in us if not (uv[0] == "c" and uv[1] == 0.0))
+            w("const T x_%d = %s;" % (pc, _mul(ipval, "(y_%d%s)" % (prw, terms))))
+        swapped = {}
+        for k, ((ra, rb), (ca, cb)) in enumerate(e.swaps):
+            swapped[ca] = (cb, k)
+            swapped[cb] = (ca, k)
+        for j in range(m.nz):
+            if j in swapped:
+                w("x[%d] = f.sw[%d] ? x_%d : x_%d;" % (j, swapped[j][1], swapped[j][0], j))
+            else:
+                w("x[%d] = x_%d;" % (j, j))
+
+    o.write("  // x = rz^{-1} b using the stored factors of factor<PIV> (b and x may alias)\n")
+    o.write("  template <bool PIV = true, class T, class F> OD_HD static void solve(const F& f, const T* b, T* x) {\n")
+    if has_state:
+        o.write("    if constexpr (PIV) {\n")
+        solve_body(el, "piv", "      ")
+        o.write("    } else {\n")
+        solve_body(els, "piv" if state_tail_piv else "static", "      ")
+        o.write("    }\n")
+    else:
+        solve_body(el, "piv", "    ")
     o.write("  }\n")
     o.write("};\n\n}  // namespace od\n")
     return o.getvalue()

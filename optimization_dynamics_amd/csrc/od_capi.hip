@@ -380,7 +380,7 @@ LaunchCfg cfg_of(const od_handle_s* h, long n) {
   LaunchCfg c;
   c.ppw = ppw_of(h, n);
   c.wpb = h->wpb > 0 ? h->wpb : 4;
-  c.coop = h->vt->has_coop && (h->coop == 2 || (h->coop == 0 && h->ppw == 0 && n <= OD_COOP_AUTO_MAX));
+  c.coop = h->vt->has_coop && (h->coop == 2 || (h->coop == 0 && h->vt->has_coop == 2 && h->ppw == 0 && n <= OD_COOP_AUTO_MAX));
   return c;
 }
 

@@ -16,7 +16,7 @@ struct ModelVT {
   double r_tol, kappa_eval, kappa_grad, eps_min, kappa_reg, gamma_reg, undercut;
   int max_iter, max_ls;
   double fric_default[4];
-  int has_coop;                                // the model has the cooperative (16 lanes per problem) state kernels
+  int has_coop;                                // cooperative (16 lanes per problem) state kernels: 0 none, 1 on request, 2 automatic for small batches
   int ngam, nbfr;                              // z indices of the impact / friction impulses
   std::array<int, 12> gam, bfr;
   hipError_t (*step_state)(const StepArgs<double>&, LaunchCfg, hipStream_t);        // pass 1, independent knots

@@ -13,6 +13,13 @@ COOP_MODELS = ["hopper", "acrobot_impact"]
 
 def test_models_with_cooperative_kernels(emu_lib):
     from optimization_dynamics_amd import models
+    hop, acro = P.make_im("hopper", emu_lib, "cpu"), P.make_im("acrobot_impact", emu_lib, "cpu")
+    uses = emu_lib.cdll.od_uses_cooperative
+    assert uses(hop._h, 4096) == 1 and uses(hop._h, 8192) == 1 and uses(hop._h, 16384) == 0       # automatic: small batches
+    assert uses(acro._h, 1024) == 0                                                                  # on request only
+    acro.set_cooperative(2); assert uses(acro._h, 1024) == 1
+    hop.set_cooperative(1); assert uses(hop._h, 64) == 0
+    hop.set_cooperative(0); hop.set_launch_config(16, 4); assert uses(hop._h, 64) == 0               # an explicit mapping wins
     im = P.make_im("cartpole_friction", emu_lib, "cpu")
     im.set_cooperative(2)                     # no cooperative kernels for this model: silently the usual ones
     X, U = W.knots("cartpole_friction", 32, seed=3)
@@ -29,8 +36,18 @@ def test_coop_matches_lane_per_problem_emulated(emu_lib, name):
 
 @pytest.mark.parametrize("name", COOP_MODELS)
 def test_coop_against_oracle_emulated(oracle, emu_lib, name):
-    im = P.make_im(name, emu_lib, "cpu")      # automatic mode picks the cooperative kernels for batches this small
-    P.check_step_grad(oracle, emu_lib, "cpu", name, 512)
+    # (automatic mode picks the cooperative kernels for hopper batches this small; the acrobot has them on request only)
+    old = P.make_im
+
+    def forced(*a, **k):
+        im = old(*a, **k)
+        im.set_cooperative(2)
+        return im
+    P.make_im = forced
+    try:
+        P.check_step_grad(oracle, emu_lib, "cpu", name, 512)
+    finally:
+        P.make_im = old
 
 
 def test_coop_rollout_emulated(oracle, emu_lib):
