@@ -145,7 +145,7 @@ def _emit(m: ModelSpec, d: Derived) -> str:
         partner.append(ZG.index(next(iter(others))) if others else -1)
         if others:
             _need(not (rz[RPSI[c], ZG[partner[c]]].free_symbols & set(z)), "psi row coefficient depends on z")
-        _need(rz[RVEL[c], sb] == -1, "velocity pivot")
+        _need(rz[RVEL[c], sb] in (-1, 1), "velocity pivot")
         _need(nzcols(RVEL[c]) <= qcols | {sb}, "velocity row pattern")
         A, B = RCA[c], RCB[c]
         _need(rz[A, ps] == z[sp_] and rz[A, sp_] == z[ps] and rz[A, b] == z[sb] and rz[A, sb] == z[b], "cone head row")
@@ -204,7 +204,7 @@ def _emit(m: ModelSpec, d: Derived) -> str:
     for i in range(NC):
         _need(force_vars([r0[RSL[i]]]) == [ZS[i]] and sp.diff(r0[RSL[i]], z[ZS[i]]) == 1, "slack residual")
     for c in range(NK):
-        _need(force_vars([r0[RVEL[c]]]) == [ZSB[c]] and sp.diff(r0[RVEL[c]], z[ZSB[c]]) == -1, "velocity residual")
+        _need(force_vars([r0[RVEL[c]]]) == [ZSB[c]] and sp.diff(r0[RVEL[c]], z[ZSB[c]]) == rz[RVEL[c], ZSB[c]], "velocity residual")
         want = z[ZPSI[c]] + (rz[RPSI[c], ZG[partner[c]]] * z[ZG[partner[c]]] if partner[c] >= 0 else 0)
         rest = sp.expand(r0[RPSI[c]] - want)
         _need(not (rest.free_symbols & zset), "psi residual")
@@ -281,6 +281,7 @@ def _emit(m: ModelSpec, d: Derived) -> str:
     for j in range(nq):
         w("    {%s},\n" % ", ".join(repr(v) for v in jfc(j)))
     w("  };\n")
+    arr("CV", [repr(v) for v in lanes16(lambda r: 0.0 if r < NC else float(rz[RVEL[r - NC], ZSB[r - NC]]), 0.0)], "double")
     for fld in ("P0", "P1", "D0", "D1"):
         arr("ZI_" + fld, [repr(v) for v in zinit(fld)], "double")
     for fld in ("P0", "P1", "D0", "D1"):

@@ -153,7 +153,7 @@ template <class CM, class RO> struct CoopLanes {
   B is_contact, is_cone, is_role, half;
   B role[CM::NC + CM::NK > 0 ? CM::NC + CM::NK : 1];
   V jfc[CM::NQ];          // constant entries of the lane's aux-row Jacobian (slack row | velocity row) w.r.t. q
-  V c_s, c_v, c_psi;      // r1 = e1 + c_s*D0 + c_v*D1 ;  r2 = c_psi*P0 + gcoef*gamma_partner + gconst
+  V c_s, c_v, c_psi;      // r1 = e1 + c_s*D0 + c_v*D1 (c_v = d(velocity row)/d s_b = +-1 on cone lanes) ;  r2 = c_psi*P0 + gcoef*gamma_partner + gconst
   V gcoef, gconst;        // psi row: d/d gamma_partner, theta-only constant (set per knot)
   OD_HD void init() {
     constexpr unsigned CB = ((1u << CM::NC) - 1u), KB = ((1u << CM::NK) - 1u) << CM::NC;
@@ -166,7 +166,7 @@ template <class CM, class RO> struct CoopLanes {
 #pragma unroll
     for (int j = 0; j < CM::NQ; ++j) jfc[j] = RO::lane_table(CM::JFC[j]);
     c_s = RO::sel(is_contact, 1.0, 0.0);
-    c_v = RO::sel(is_cone, -1.0, 0.0);
+    c_v = RO::lane_table(CM::CV);
     c_psi = RO::sel(is_cone, 1.0, 0.0);
     gcoef = V(0.0);
     gconst = V(0.0);
@@ -339,8 +339,10 @@ OD_HD bool coop_eval_factor(const CoopLanes<CM, RO>& L, const CoopVec<CM::NQ, ty
     V qA[NQ], qB[NQ];
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
-      qA[j] = CM::UPV[j] ? z.P1 * f.JF[j] : V(0.0);
-      qB[j] = CM::UPV[j] ? z.P0 * f.JF[j] : V(0.0);
+      // s_b eliminated through its velocity row (c_v d s_b + JF . dq = r_v, c_v = +-1): d s_b = c_v (r_v - JF . dq)
+      const V nJ = -(L.c_v * f.JF[j]);
+      qA[j] = CM::UPV[j] ? z.P1 * nJ : V(0.0);
+      qB[j] = CM::UPV[j] ? z.P0 * nJ : V(0.0);
       if constexpr (CM::SH > 0) {
         if (CM::UPJ[j]) {
           const V tp = RO::template shr<CM::SH>(f.t[j]);
@@ -398,8 +400,9 @@ OD_HD void coop_solve(const CoopLanes<CM, RO>& L, const CoopFact<CM, RO>& f, con
   if constexpr (CM::NC > 0) ty = f.ipc * y;
   // forward: cones
   if constexpr (CM::NK > 0) {
-    V yA = r.rA - z.D0 * r.r2 + z.P1 * r.r1;
-    V yB = r.rB - z.D1 * r.r2 + z.P0 * r.r1;
+    const V nr1 = L.c_v * r.r1;
+    V yA = r.rA - z.D0 * r.r2 - z.P1 * nr1;
+    V yB = r.rB - z.D1 * r.r2 - z.P0 * nr1;
     if constexpr (CM::SH > 0) {
       const V typ = RO::template shr<CM::SH>(ty);
       yA = yA - f.gA * typ;
@@ -434,7 +437,7 @@ OD_HD void coop_solve(const CoopLanes<CM, RO>& L, const CoopFact<CM, RO>& f, con
     // arithmetic of a contact lane may overflow when gamma or s underflow, and 0 * inf would poison its rows)
     x.P1 = RO::sel(L.is_cone, db, 0.0);
     x.D0 = RO::sel(L.is_cone, dsp, a1);
-    x.D1 = RO::sel(L.is_cone, -a1, 0.0);
+    x.D1 = RO::sel(L.is_cone, L.c_v * a1, 0.0);
   } else {
     x.P0 = dg; x.P1 = V(0.0); x.D0 = a1; x.D1 = V(0.0);
   }
@@ -698,6 +701,45 @@ template <class CM, class RO> OD_HD void coop_unit_rollout_state(const RolloutAr
       for (int i = 0; i < M::NU; ++i) un[i] = a.u.at(i, k + a.B);
     }
     coop_knot_state<CM, RO>(L, a, k, x, u, q3);
+#pragma unroll
+    for (int i = 0; i < nq; ++i) { x[i] = x[nq + i]; x[nq + i] = q3[i]; }
+  }
+}
+
+// closed-loop rollout = forward pass of iLQR (od_units.h::unit_rollout_policy): candidate p = a*Bnom + b follows the
+// nominal trajectory b with step size alphas[a], u_t = ubar_t + alpha k_t + K_t (x_t - xbar_t); one candidate per row
+template <class CM, class RO> OD_HD void coop_unit_rollout_policy(const PolicyArgs<double>& pa, long p) {
+  using M = typename CM::M;
+  constexpr int nq = M::NQ, n = 2 * M::NQ, nu = M::NU > 0 ? M::NU : 1;
+  const StepArgs<double>& a = pa.r.s;
+  const long b = p % pa.Bnom;
+  const double alpha = pa.alphas[p / pa.Bnom];
+  double x[n], u[nu], q3[nq];
+#pragma unroll
+  for (int i = 0; i < n; ++i) x[i] = a.x.at(i, b);
+  if (pa.r.x0.ok() && RO::first_lane()) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) pa.r.x0.at(i, p) = x[i];
+  }
+  CoopLanes<CM, RO> L;
+  L.init();
+  for (int t = 0; t < pa.r.Tn; ++t) {
+    const long kn = (long)t * pa.Bnom + b, kc = (long)t * a.B + p;
+    double dx[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) dx[i] = x[i] - pa.xbar.at(i, kn);
+#pragma unroll
+    for (int j = 0; j < M::NU; ++j) u[j] = pa.ubar.at(j, kn) + alpha * pa.kff.at(j, kn);
+#pragma unroll
+    for (int i = 0; i < n; ++i) {            // K is nu x n col-major: column i multiplies dx[i]
+#pragma unroll
+      for (int j = 0; j < M::NU; ++j) u[j] += pa.K.at(j + M::NU * i, kn) * dx[i];
+    }
+    if (RO::first_lane()) {
+#pragma unroll
+      for (int j = 0; j < M::NU; ++j) pa.U.at(j, kc) = u[j];
+    }
+    coop_knot_state<CM, RO>(L, a, kc, x, u, q3);
 #pragma unroll
     for (int i = 0; i < nq; ++i) { x[i] = x[nq + i]; x[nq + i] = q3[i]; }
   }

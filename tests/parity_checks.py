@@ -547,3 +547,35 @@ def check_coop_rollout(oracle, lib, device, B, T):
     im.set_cooperative(1)
     X1, _, _, st1, it1, _ = im.rollout(torch.tensor(x1, device=device), torch.tensor(U, device=device))
     assert (it1 == it).double().mean().item() > 0.995       # a differing count needs a knot at the edge of a tolerance
+
+
+def check_coop_policy_rollout(lib, device, B=6, T=12, na=3):
+    """closed-loop rollouts (iLQR forward pass, od_rollout_policy) through the cooperative kernel against the
+    lane-per-problem one: same controls applied, same states to rounding"""
+    from optimization_dynamics_amd.dynamics import _ptr
+    x1, U = W.hopper_rollout_inputs(B, T, seed=4, u_sigma=0.3)
+    im = make_im("hopper", lib, device)
+    dev = im.device
+    x1d, Ud = torch.tensor(x1, device=dev), torch.tensor(U, device=dev)
+    im.set_cooperative(1)
+    X = im.rollout(x1d, Ud, grads=False)[0]
+    n, m = 8, 2
+    rng = np.random.default_rng(2)
+    K = torch.tensor(0.05 * rng.normal(size=(m * n, T, B)), device=dev)
+    k = torch.tensor(0.1 * rng.normal(size=(m, T, B)), device=dev)
+    alphas = torch.tensor([1.0, 0.5, 0.0], dtype=torch.float64, device=dev)
+    out = {}
+    for mode in (1, 2):
+        im.set_cooperative(mode)
+        im._use_current_stream()
+        Xc = torch.empty(n, T + 1, na * B, dtype=torch.float64, device=dev)
+        Uc = torch.empty(m, T, na * B, dtype=torch.float64, device=dev)
+        st = torch.empty(T, na * B, dtype=torch.int32, device=dev)
+        lib.check(lib.cdll.od_rollout_policy(im._h, B, T, na, _ptr(alphas), _ptr(x1d.contiguous()), _ptr(X.contiguous()),
+                                             _ptr(Ud.contiguous()), _ptr(K), _ptr(k), _ptr(Xc), _ptr(Uc), _ptr(st), 0))
+        im.synchronize()
+        out[mode] = (Xc.cpu().numpy(), Uc.cpu().numpy(), st.cpu().numpy())
+    assert np.array_equal(out[1][2], out[2][2])
+    assert np.abs(out[1][0] - out[2][0]).max() < 1e-7 and np.abs(out[1][1] - out[2][1]).max() < 1e-7
+    # alpha = 0 with x = xbar reproduces the nominal trajectory (the feedback term vanishes)
+    assert np.abs(out[2][0][:, :, 2 * B:] - X.cpu().numpy()).max() < 1e-7

@@ -8,7 +8,7 @@ import torch
 import parity_checks as P
 import workloads as W
 
-COOP_MODELS = ["hopper", "acrobot_impact"]
+COOP_MODELS = ["hopper", "acrobot_impact", "cartpole_friction"]
 
 
 def test_models_with_cooperative_kernels(emu_lib):
@@ -20,9 +20,12 @@ def test_models_with_cooperative_kernels(emu_lib):
     acro.set_cooperative(2); assert uses(acro._h, 1024) == 1
     hop.set_cooperative(1); assert uses(hop._h, 64) == 0
     hop.set_cooperative(0); hop.set_launch_config(16, 4); assert uses(hop._h, 64) == 0               # an explicit mapping wins
-    im = P.make_im("cartpole_friction", emu_lib, "cpu")
-    im.set_cooperative(2)                     # no cooperative kernels for this model: silently the usual ones
-    X, U = W.knots("cartpole_friction", 32, seed=3)
+    im = P.make_im("planar_push", emu_lib, "cpu")
+    im.set_cooperative(2)                     # no cooperative kernels for this model (3-d cones): silently the usual ones
+    assert uses(im._h, 64) == 0
+    im = P.make_im("cartpole_frictionless", emu_lib, "cpu")
+    im.set_cooperative(2)
+    X, U = W.knots("cartpole_frictionless", 32, seed=3)
     a = im.step(torch.tensor(X), torch.tensor(U))[0]
     im.set_cooperative(1)
     assert torch.equal(a, im.step(torch.tensor(X), torch.tensor(U))[0])
@@ -65,6 +68,15 @@ def test_coop_finite_undercut_emulated(oracle, emu_lib):
     b = [t.numpy() for t in im.step_grad(torch.tensor(X), torch.tensor(U))]
     assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
     assert np.abs(a[0] - b[0]).max() < 1e-8
+
+
+def test_coop_policy_rollout_emulated(emu_lib):
+    P.check_coop_policy_rollout(emu_lib, "cpu")
+
+
+@pytest.mark.gpu
+def test_coop_policy_rollout(gpu_lib):
+    P.check_coop_policy_rollout(gpu_lib, "cuda:0", B=16, T=20)
 
 
 @pytest.mark.gpu
