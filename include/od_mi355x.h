@@ -127,7 +127,9 @@ int od_step_grad_compact(od_handle h, long B, const void* x, const void* u, void
  * solver's per-knot fx/fu calls) for B trajectories of T steps: launch 1 runs the time recursion on the
  * device, launch 2 all T*B implicit gradients in parallel.
  * x1: 2nq per trajectory; U: nu per knot (T*B knots); X: 2nq per slot ((T+1)*B slots, slot 0 = x1);
- * A: 2nq x 2nq per knot; Bm: 2nq x nu per knot.  A, Bm, status (T*B), iters (2*T*B) may be NULL. */
+ * A: 2nq x 2nq per knot; Bm: 2nq x nu per knot.  A, Bm, status (T*B), iters (2*T*B) may be NULL.
+ * With a finite undercut (and cones, and kappa_eval != kappa_grad) a third launch solves every knot again at
+ * kappa_grad from its rolled-out state, as the reference's fx / fu do (status / iterations merged as in od_step_grad). */
 int od_rollout(od_handle h, long B, int T, const void* x1, const void* U, void* X, void* A, void* Bm,
                int* status, int* iters);
 /* the same two launches with the linearisation in compact form: dq3 = d q3 / d(q1, q2, u1), nq x (2nq+nu) column-major

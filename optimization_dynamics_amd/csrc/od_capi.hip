@@ -763,11 +763,11 @@ static int rollout_impl(od_handle h, const char* fn, long B, int T, const void* 
   if (B <= 0 || T <= 0) return OD_OK;
   if (!x1 || !U || !X) return fail(OD_ERR_INVALID, std::string(fn) + ": null x1/U/X");
   const int want_grad = (A || Bm || dq3) ? 1 : 0;
-  if (!fusable(h) && want_grad) return fail(OD_ERR_UNSUPPORTED, std::string(fn) + ": finite undercut with kappa_eval != kappa_grad");
+  const bool fused = fusable(h);
   const int n = 2 * h->vt->nq, nz = h->vt->nz;
   const long K = (long)T * B;
   RolloutArgs<double> r;
-  r.s = step_args(h, B, K, x1, U, nullptr, A, Bm, dq3, status, iters, want_grad);
+  r.s = step_args(h, B, K, x1, U, nullptr, A, Bm, dq3, status, iters, (want_grad && fused) ? 1 : 0);
   // X has (T+1)*B slots; knot k's d = [q2; q3] goes to slot k + B
   View<double> xv = mkview<double>(X, n, (long)(T + 1) * B, h->layout);
   r.x0 = xv;
@@ -782,6 +782,19 @@ static int rollout_impl(od_handle h, const char* fn, long B, int T, const void* 
   if (!want_grad) return OD_OK;
   View<const double> xin;
   xin.p = xv.p; xin.se = xv.se; xin.sb = xv.sb;                        // state of knot k = slot k of X
+  if (!fused) {
+    // finite undercut with kappa_eval != kappa_grad: the reference's grad simulator iterates differently from its eval
+    // simulator, so every knot is solved again at kappa_grad from its rolled-out state (all K knots in parallel), like
+    // fx / fu called on the states of iLQR.rollout; status / iterations of that solve are merged in
+    StepArgs<double> g = r.s;
+    g.B = K;
+    g.x = xin;
+    g.d.p = nullptr;
+    g.want_grad = 1;
+    g.merge_grad_status = 1;
+    g.opts.kappa_eval = g.opts.kappa_grad;
+    OD_HIP(h->vt->step_state(g, cfg_of(h, K), h->stream));
+  }
   return run_grad_pass(h, r.s, K, xin);                                // pass 2: all T*B gradients
 }
 

@@ -579,3 +579,20 @@ def check_coop_policy_rollout(lib, device, B=6, T=12, na=3):
     assert np.abs(out[1][0] - out[2][0]).max() < 1e-7 and np.abs(out[1][1] - out[2][1]).max() < 1e-7
     # alpha = 0 with x = xbar reproduces the nominal trajectory (the feedback term vanishes)
     assert np.abs(out[2][0][:, :, 2 * B:] - X.cpu().numpy()).max() < 1e-7
+
+
+def check_rollout_finite_undercut(oracle, lib, device, B=6, T=8):
+    """od_rollout with a finite undercut (the two simulators of the reference iterate differently): states from the eval
+    solves of the recursion, gradients from separate grad solves on those states -- equal to od_step_grad on each knot"""
+    name = "hopper"
+    x1, U = W.hopper_rollout_inputs(B, T, seed=12, u_sigma=0.3)
+    im = make_im(name, lib, device, options=dict(undercut=5.0))
+    X, A, Bm, st, it, _ = im.rollout(torch.tensor(x1, device=device), torch.tensor(U, device=device))
+    for t in range(T):
+        D, DX, DU, s1, i1 = im.step_grad(X[:, t], torch.tensor(U[:, t], device=device))
+        assert torch.equal(D, X[:, t + 1]) and torch.equal(s1, st[t]) and torch.equal(i1, it[:, t])
+        assert torch.equal(DX, A[:, :, t]) and torch.equal(DU, Bm[:, :, t])
+    Do, DXo, DUo, bad = oracle.step_grad_batch(make_sim(oracle, name, undercut=5.0), X[:, 0].cpu().numpy(), U[:, 0])
+    ok = (st[0].cpu().numpy() & 3) == 3
+    assert np.abs(X[:, 1].cpu().numpy() - Do)[:, ok].max() < STATE_TOL
+    assert_grad_close(np.concatenate([A[:, :, 0].cpu().numpy(), Bm[:, :, 0].cpu().numpy()], 1), np.concatenate([DXo, DUo], 1), ok, "finite undercut rollout")

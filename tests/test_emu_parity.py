@@ -227,3 +227,7 @@ def test_tail_lu_against_numpy(emu_lib):
     Af = np.asfortranarray(A)
     ok = fn(Af.ctypes.data_as(P), b.ctypes.data_as(P), x.ctypes.data_as(P))
     assert ok == 0 and np.all(np.isfinite(x)) and x[0] == 0.0
+
+
+def test_rollout_with_finite_undercut(oracle, emu_lib):
+    P.check_rollout_finite_undercut(oracle, emu_lib, "cpu")
