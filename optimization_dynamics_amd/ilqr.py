@@ -141,6 +141,11 @@ class ILQR:
             for it in range(max_iter):
                 quad = obj.expansion(X, U, lam, rho)
                 K, k, dV, bst = self.backward(A, Bm, quad, reg)
+                # a backward pass whose Quu + reg I was not positive definite clamps its pivot and returns useless gains:
+                # raise the regularisation and repeat it before spending a forward pass on them
+                while (bst != 1).any() and reg < 1e6:
+                    reg = min(max(reg, 1e-8) * 10.0, 1e6)
+                    K, k, dV, bst = self.backward(A, Bm, quad, reg)
                 Xc, Uc, cst = self.forward(x1, X, U, K, k)
                 Jc = obj.value(Xc, Uc, None if lam is None else lam.repeat(1, na), rho).view(na, B)
                 ok_roll = ((cst & 1) == 1).all(0).view(na, B)
@@ -152,8 +157,9 @@ class ILQR:
                 U = torch.where(took[None, None, :], Uc[:, :, sel], U)
                 Jn = torch.where(took, Jc.reshape(-1)[sel], J)
                 dJ = (J - Jn)
-                X, A, Bm, st = self.linearize(x1, U)
-                J = obj.value(X, U, lam, rho)
+                if took.any():                                   # nothing moved: the linearisation is still valid
+                    X, A, Bm, st = self.linearize(x1, U)
+                    J = obj.value(X, U, lam, rho)
                 history.append(J.clone())
                 if verbose:
                     print("al %d it %d  J mean %.6g  accepted %d/%d  max dJ %.3g" % (al, it, J.mean().item(), int(took.sum()), B, dJ.max().item()))
