@@ -329,28 +329,54 @@ def _emit(m: ModelSpec, d: Derived) -> str:
         for k in range(nq):
             w("    nbv[%d][%d] = %s;\n" % (c, k, aref(RDYN[k], ZB[c])))
     w("  }\n")
+    # couplings that are compile-time constants are passed as shared literal operands (one register pair for every 1.0
+    # in a block instead of one per entry); a negative constant flips fmac <-> fnmac
+    consts = {}
+
+    def coupling(kind, row, col, name):
+        """(op kind, multiplier operand) for  acc (+|-)= src * rz[row, col]"""
+        e = rz[row, col]
+        if e.is_Number:
+            c = float(e)
+            if c < 0:
+                kind = "fnmac" if kind == "fmac" else "fmac"
+            sym = consts.setdefault(abs(c), "kc%d_" % len(consts))
+            return kind, sym
+        return kind, name
+
+    def const_decls():
+        return "".join("    const double %s = %r;\n" % (sym, c) for c, sym in consts.items())
+
     w("  // Schur complement of the dynamics rows: d gamma_i = ty_i + t_i . dq,  d b_c = Wy_c - W_c . dq\n")
     w("  template <class RO, class F> OD_HD static void schur(const F& f, const typename RO::V* W, double* dqq) {\n")
     ops = []
+    consts.clear()
     for i in range(NC):
         for k in PN[i]:
+            kind, mul = coupling("fmac", RDYN[k], ZG[i], "f.nv[%d][%d]" % (i, k))
             for j in PJ[i]:
-                ops.append(("fmac", i, "dqq[%d]" % (k + nq * j), "f.t[%d]" % j, "f.nv[%d][%d]" % (i, k)))
+                ops.append((kind, i, "dqq[%d]" % (k + nq * j), "f.t[%d]" % j, mul))
     for c in range(NK):
         wj = sorted(set(PJV[c]) | (set(PJ[partner[c]]) if partner[c] >= 0 else set()))
         for k in PNB[c]:
+            kind, mul = coupling("fnmac", RDYN[k], ZB[c], "f.nbv[%d][%d]" % (c, k))
             for j in wj:
-                ops.append(("fnmac", NC + c, "dqq[%d]" % (k + nq * j), "W[%d]" % j, "f.nbv[%d][%d]" % (c, k)))
+                ops.append((kind, NC + c, "dqq[%d]" % (k + nq * j), "W[%d]" % j, mul))
+    w(const_decls())
     w(_dpp_block(ops))
     w("  }\n")
     w("  template <class RO, class F> OD_HD static void rhs_update(const F& f, const typename RO::V& ty, const typename RO::V& Wy, double* rd) {\n")
     ops = []
+    consts.clear()
     for i in range(NC):
         for k in PN[i]:
-            ops.append(("fnmac", i, "rd[%d]" % k, "ty", "f.nv[%d][%d]" % (i, k)))
+            kind, mul = coupling("fnmac", RDYN[k], ZG[i], "f.nv[%d][%d]" % (i, k))
+            ops.append((kind, i, "rd[%d]" % k, "ty", mul))
     for c in range(NK):
         for k in PNB[c]:
-            ops.append(("fnmac", NC + c, "rd[%d]" % k, "Wy", "f.nbv[%d][%d]" % (c, k)))
+            kind, mul = coupling("fnmac", RDYN[k], ZB[c], "f.nbv[%d][%d]" % (c, k))
+            ops.append((kind, NC + c, "rd[%d]" % k, "Wy", mul))
+    w(const_decls())
     w(_dpp_block(ops))
     w("  }\n")
     w("  // psi rows: psi_c + g[c] * gamma_partner + gc[c] (theta only)\n")
