@@ -447,38 +447,61 @@ OD_HD void coop_solve(const CoopLanes<CM, RO>& L, const CoopFact<CM, RO>& f, con
 // ---------------------------------------------------------------------------------------------------------------
 // step length, centering, correction
 // ---------------------------------------------------------------------------------------------------------------
-// CVXOPT sec. 8.2 step for a two-dimensional cone (od_solver.h::soc_step_one<2>), lane-parallel
-template <class RO> OD_HD typename RO::V coop_soc_step2(typename RO::V l0, typename RO::V l1, typename RO::V d0, typename RO::V d1, double tau) {
+// CVXOPT sec. 8.2 step for a two-dimensional cone (od_solver.h::soc_step_one<2>), lane-parallel.  Everything that
+// depends on the cone variable alone -- not on the direction -- is computed once per iterate (StepPre) and serves the
+// predictor's and the corrector's step length: 1/sqrt(l0^2 - l1^2) with its guards, its square, 1/(l0/sqrt(.) + 1).
+template <class RO> struct StepPre {
+  typename RO::V zz;             // contacts: gamma (lanes 0..7) | s (mirrors)
+  typename RO::V l0, l1;         // cones: primal (lanes 0..7) | dual (mirrors) member
+  typename RO::V isq, ill, rc1;
+};
+
+template <class CM, class RO>
+OD_HD StepPre<RO> coop_step_pre(const CoopLanes<CM, RO>& L, const CoopVec<CM::NQ, typename RO::V>& z) {
   using V = typename RO::V;
-  const double eps = 1e-14;
-  V ll = l0 * l0, ld = l0 * d0;
-  ll = ll - l1 * l1;
-  ld = ld - l1 * d1;
-  ll = od_fmax(ll, V(1e-25)) + eps;
-  ld = ld + eps;
-  const V isq = od_rsqrt(ll), ill = isq * isq;
-  const V rs = ld * ill;
-  const V c = (ld * isq + d0) * od_rcp(l0 * isq + 1.0);
-  const V nv = od_abs(d1 * isq - c * l1 * ill);
+  StepPre<RO> p;
+  p.zz = RO::sel(L.half, z.D0, z.P0);
+  p.l0 = p.zz;
+  p.l1 = RO::sel(L.half, z.D1, z.P1);
+  if constexpr (CM::NK > 0) {
+    V ll = p.l0 * p.l0;
+    ll = ll - p.l1 * p.l1;
+    ll = od_fmax(ll, V(1e-25)) + 1e-14;
+    p.isq = od_rsqrt(ll);
+    p.ill = p.isq * p.isq;
+    p.rc1 = od_rcp(p.l0 * p.isq + 1.0);
+  } else {
+    p.isq = p.ill = p.rc1 = V(0.0);
+  }
+  return p;
+}
+
+template <class RO> OD_HD typename RO::V coop_soc_step2(const StepPre<RO>& p, typename RO::V d0, typename RO::V d1, double tau) {
+  using V = typename RO::V;
+  V ld = p.l0 * d0;
+  ld = ld - p.l1 * d1;
+  ld = ld + 1e-14;
+  const V rs = ld * p.ill;
+  const V c = (ld * p.isq + d0) * p.rc1;
+  const V nv = od_abs(d1 * p.isq - c * p.l1 * p.ill);
   const V den = nv - rs;
   return RO::sel(den > 0.0, tau * od_rcp(den), 1.0);      // the caller caps at 1
 }
 
 template <class CM, class RO>
-OD_HD double coop_step_length(const CoopLanes<CM, RO>& L, const CoopVec<CM::NQ, typename RO::V>& z, const CoopVec<CM::NQ, typename RO::V>& d,
+OD_HD double coop_step_length(const CoopLanes<CM, RO>& L, const StepPre<RO>& p, const CoopVec<CM::NQ, typename RO::V>& d,
                               double tau_ort, double tau_soc) {
   using V = typename RO::V;
   V a = V(1.0);
+  const V d0h = RO::sel(L.half, d.D0, d.P0);
   if constexpr (CM::NC > 0) {
     // lanes 0..7 test gamma, their mirrors test s:  alpha <= tau * z / d  where d > 0
-    const V zz = RO::sel(L.half, z.D0, z.P0), dd = RO::sel(L.half, d.D0, d.P0);
-    const V ao = RO::sel(dd > 0.0, (tau_ort * zz) * od_rcp(dd), 1.0);
+    const V ao = RO::sel(d0h > 0.0, (tau_ort * p.zz) * od_rcp(d0h), 1.0);
     a = RO::sel(L.is_contact, ao, a);
   }
   if constexpr (CM::NK > 0) {
-    const V l0 = RO::sel(L.half, z.D0, z.P0), l1 = RO::sel(L.half, z.D1, z.P1);
-    const V d0 = -RO::sel(L.half, d.D0, d.P0), d1 = -RO::sel(L.half, d.D1, d.P1);
-    a = RO::sel(L.is_cone, coop_soc_step2<RO>(l0, l1, d0, d1, tau_soc), a);
+    const V d1h = RO::sel(L.half, d.D1, d.P1);
+    a = RO::sel(L.is_cone, coop_soc_step2<RO>(p, -d0h, -d1h, tau_soc), a);
   }
   a = od_fmin(a, V(1.0));
   a = half_min<RO>(a);
@@ -524,8 +547,9 @@ OD_HD void coop_iteration(const CoopLanes<CM, RO>& L, const Opts<double>& o, con
   if (!coop_eval_factor<CM, PIV, RO>(L, z, th, pre, tr, reg, f)) status &= ~OD_ST_FACTOR_OK;
   Vec D;
   coop_solve<CM, PIV, RO>(L, f, z, r, D);
+  const StepPre<RO> sp = coop_step_pre<CM, RO>(L, z);
   if constexpr (CONES) {
-    const double aaff = coop_step_length<CM, RO>(L, z, D, 1.0, 1.0);
+    const double aaff = coop_step_length<CM, RO>(L, sp, D, 1.0, 1.0);
     double kap = coop_centering<CM, RO>(L, z, D, aaff);
     kap = od_fmax(kap, o.kappa_eval * o.undercut_inv);
     // r(z; kappa) from r(z; 0) on the head rows, then the second-order correction of the predictor
@@ -535,7 +559,7 @@ OD_HD void coop_iteration(const CoopLanes<CM, RO>& L, const Opts<double>& o, con
   }
   const double vio = od_fmax(r_vio, k_vio);
   const double tau = 1.0 - od_fmin(o.eps_min, vio * vio);
-  double alpha = coop_step_length<CM, RO>(L, z, D, tau, od_fmin(tau, 0.99));
+  double alpha = coop_step_length<CM, RO>(L, sp, D, tau, od_fmin(tau, 0.99));
   // backtracking until either violation does not increase (od_solver.h::line_search, sequential form)
   Vec zc;
   Res rc;
