@@ -78,10 +78,18 @@ struct RowEmu {
   static V xor1(const V& x) { V r; for (int i = 0; i < 16; ++i) r.v[i] = x.v[i ^ 1]; return r; }
   static V xor2(const V& x) { V r; for (int i = 0; i < 16; ++i) r.v[i] = x.v[i ^ 2]; return r; }
   static V half_mirror(const V& x) { V r; for (int i = 0; i < 16; ++i) r.v[i] = x.v[(i & 8) | (7 - (i & 7))]; return r; }
-  template <class View_> static void store(const View_& v, const int (&idx)[16], long k, const V& x) {
-    for (int i = 0; i < 8; ++i) if (idx[i] >= 0) v.at(idx[i], k) = x.v[i];
+  // four destination-row tables (one per lane vector; -1 = lane holds nothing to store) packed into one int per lane
+  struct I { int v[16]; };
+  static I lane_pack4(const int (&a)[16], const int (&b)[16], const int (&c)[16], const int (&d)[16]) {
+    I r;
+    for (int i = 0; i < 16; ++i) r.v[i] = (a[i] & 0xFF) | ((b[i] & 0xFF) << 8) | ((c[i] & 0xFF) << 16) | ((d[i] & 0xFF) << 24);
+    return r;
+  }
+  template <int W, class View_> static void store(const View_& v, const I& idx, long k, const V& x) {
+    for (int i = 0; i < 8; ++i) { const int j = (idx.v[i] >> (8 * W)) & 0xFF; if (j != 0xFF) v.at(j, k) = x.v[i]; }
   }
   static bool first_lane() { return true; }
+  static void arrived(const double&) {}
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -127,12 +135,19 @@ struct RowDev {
   __device__ __forceinline__ static double xor1(double x) { return dpp32<0xB1>(x); }          // quad_perm [1,0,3,2]
   __device__ __forceinline__ static double xor2(double x) { return dpp32<0x4E>(x); }          // quad_perm [2,3,0,1]
   __device__ __forceinline__ static double half_mirror(double x) { return dpp32<0x141>(x); }  // lane l <-> 7-l within 8
-  template <class View_> __device__ __forceinline__ static void store(const View_& v, const int (&idx)[16], long k, double x) {
+  // the tables are read once per kernel (CoopLanes::init): a lookup per store is a dependent memory round trip per knot
+  using I = int;
+  __device__ __forceinline__ static I lane_pack4(const int (&a)[16], const int (&b)[16], const int (&c)[16], const int (&d)[16]) {
     const int l = lane();
-    const int i = idx[l];
-    if (l < 8 && i >= 0) v.at(i, k) = x;
+    return (a[l] & 0xFF) | ((b[l] & 0xFF) << 8) | ((c[l] & 0xFF) << 16) | ((d[l] & 0xFF) << 24);
+  }
+  template <int W, class View_> __device__ __forceinline__ static void store(const View_& v, I idx, long k, double x) {
+    const int i = (idx >> (8 * W)) & 0xFF;
+    if (lane() < 8 && i != 0xFF) v.at(i, k) = x;
   }
   __device__ __forceinline__ static bool first_lane() { return lane() == 0; }
+  // the value of an earlier load is needed from here on (places the s_waitcnt)
+  __device__ __forceinline__ static void arrived(const double& x) { asm volatile("" ::"v"(x)); }
 };
 #endif
 
@@ -155,7 +170,9 @@ template <class CM, class RO> struct CoopLanes {
   V jfc[CM::NQ];          // constant entries of the lane's aux-row Jacobian (slack row | velocity row) w.r.t. q
   V c_s, c_v, c_psi;      // r1 = e1 + c_s*D0 + c_v*D1 (c_v = d(velocity row)/d s_b = +-1 on cone lanes) ;  r2 = c_psi*P0 + gcoef*gamma_partner + gconst
   V gcoef, gconst;        // psi row: d/d gamma_partner, theta-only constant (set per knot)
+  typename RO::I zg_idx;  // rows of z the lane's (P0, P1, D0, D1) go to in the gradient hand-over
   OD_HD void init() {
+    zg_idx = RO::lane_pack4(CM::IDX_P0, CM::IDX_P1, CM::IDX_D0, CM::IDX_D1);
     constexpr unsigned CB = ((1u << CM::NC) - 1u), KB = ((1u << CM::NK) - 1u) << CM::NC;
     is_contact = RO::lane_flag(CB | (CB << 8));
     is_cone = RO::lane_flag(KB | (KB << 8));
@@ -632,12 +649,13 @@ template <class CM, class RO> struct CoopDefer {
   using V = typename RO::V;
   const View<double>& zg;
   long k;
+  typename RO::I idx;
   OD_HD void operator()(const CoopVec<CM::NQ, V>& z, double reg) const {
     if (!zg.ok()) return;
-    RO::store(zg, CM::IDX_P0, k, z.P0);
-    RO::store(zg, CM::IDX_P1, k, z.P1);
-    RO::store(zg, CM::IDX_D0, k, z.D0);
-    RO::store(zg, CM::IDX_D1, k, z.D1);
+    RO::template store<0>(zg, idx, k, z.P0);
+    RO::template store<1>(zg, idx, k, z.P1);
+    RO::template store<2>(zg, idx, k, z.D0);
+    RO::template store<3>(zg, idx, k, z.D1);
     if (RO::first_lane()) {
 #pragma unroll
       for (int i = 0; i < CM::NQ; ++i) zg.at(CM::ZQ[i], k) = z.q[i];
@@ -646,8 +664,13 @@ template <class CM, class RO> struct CoopDefer {
   }
 };
 
-template <class CM, class RO>
-OD_HD void coop_knot_state(const CoopLanes<CM, RO>& L0, const StepArgs<double>& a, long k, const double* xin, const double* uin, double* q3out) {
+struct CoopNoHook { OD_HD void operator()() const {} };
+// `before_stores` runs between the solve and the knot's stores: a rollout waits there for its prefetched next control,
+// while the only memory operations in flight are a knot old (the wait counter is in order: after the stores it would
+// wait for them as well, one store round trip per knot)
+template <class CM, class RO, class Hook = CoopNoHook>
+OD_HD void coop_knot_state(const CoopLanes<CM, RO>& L0, const StepArgs<double>& a, long k, const double* xin, const double* uin, double* q3out,
+                           const Hook& before_stores = Hook()) {
   using M = typename CM::M;
   using V = typename RO::V;
   constexpr int nq = M::NQ;
@@ -660,11 +683,12 @@ OD_HD void coop_knot_state(const CoopLanes<CM, RO>& L0, const StepArgs<double>& 
   for (int i = 0; i < nq; ++i) z.q[i] = z0[CM::ZQ[i]];
   z.P0 = RO::lane_table(CM::ZI_P0); z.P1 = RO::lane_table(CM::ZI_P1);
   z.D0 = RO::lane_table(CM::ZI_D0); z.D1 = RO::lane_table(CM::ZI_D1);
-  CoopDefer<CM, RO> defer{a.zg, k};
+  CoopDefer<CM, RO> defer{a.zg, k, L0.zg_idx};
   int it[2];
   const int st = coop_ip_step<CM, RO>(L, a.opts, th, z, a.want_grad != 0, defer, it);
 #pragma unroll
   for (int i = 0; i < nq; ++i) q3out[i] = z.q[i];
+  before_stores();
   if (RO::first_lane()) {
     if (a.d.ok()) {
       auto c = a.d.cursor(k);
@@ -724,7 +748,10 @@ template <class CM, class RO> OD_HD void coop_unit_rollout_state(const RolloutAr
 #pragma unroll
       for (int i = 0; i < M::NU; ++i) un[i] = a.u.at(i, k + a.B);
     }
-    coop_knot_state<CM, RO>(L, a, k, x, u, q3);
+    coop_knot_state<CM, RO>(L, a, k, x, u, q3, [&]() {
+#pragma unroll
+      for (int i = 0; i < M::NU; ++i) RO::arrived(un[i]);
+    });
 #pragma unroll
     for (int i = 0; i < nq; ++i) { x[i] = x[nq + i]; x[nq + i] = q3[i]; }
   }

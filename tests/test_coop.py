@@ -37,6 +37,18 @@ def test_coop_matches_lane_per_problem_emulated(emu_lib, name):
     P.check_coop_vs_serial(emu_lib, "cpu", name, 1024)
 
 
+@pytest.mark.parametrize("B", [3, 1027, 2051])
+def test_coop_rows_per_wavefront_emulated(emu_lib, B):
+    """batches of <= 1024, <= 2048 and more problems run 1, 2 and 4 rows per wavefront: same results, problem by problem"""
+    X, U = W.knots("hopper", 2051, seed=83)
+    im = P.make_im("hopper", emu_lib, "cpu")
+    im.set_cooperative(2)
+    full = im.step_grad(torch.tensor(X), torch.tensor(U))
+    part = im.step_grad(torch.tensor(np.ascontiguousarray(X[:, :B])), torch.tensor(np.ascontiguousarray(U[:, :B])))
+    for a, b in zip(full, part):
+        assert torch.equal(a[..., :B], b)
+
+
 @pytest.mark.parametrize("name", COOP_MODELS)
 def test_coop_against_oracle_emulated(oracle, emu_lib, name):
     # (automatic mode picks the cooperative kernels for hopper batches this small; the acrobot has them on request only)
@@ -91,9 +103,9 @@ def test_coop_rollout(oracle, gpu_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [1, 3, 5, 63, 257])
+@pytest.mark.parametrize("B", [1, 3, 5, 63, 257, 1025, 2047, 2051])
 def test_coop_ragged_batches(gpu_lib, B):
-    """rows of a wavefront / wavefronts of a workgroup without a problem"""
+    """rows of a wavefront / wavefronts of a workgroup without a problem, with 1, 2 and 4 rows per wavefront"""
     X, U = W.knots("hopper", B, seed=81)
     im = P.make_im("hopper", gpu_lib, "cuda:0")
     Xd, Ud = torch.tensor(X, device="cuda:0"), torch.tensor(U, device="cuda:0")
