@@ -84,15 +84,15 @@ OD_HD float od_sqrt(float x) { return sqrtf(x); }
 OD_HD float od_abs(float x) { return fabsf(x); }
 OD_HD float od_pow(float x, float y) { return powf(x, y); }
 
-// reciprocal: hardware seed + Newton refinement on the device (about 1 ulp, no denormal / inf
-// special-casing -- operands here are pivots, norms and step denominators), plain division on host
+// reciprocal: hardware seed (v_rcp_f64: 24 bits, tools/ubench/rcp_accuracy.hip) + one third-order step
+// r (1 + e + e^2), e = 1 - x r, on the device -- within 0.5 ulp, and bit for bit what two or three Newton steps give
+// (1 M random operands, profiles/r2_ubench_rcp_accuracy.txt) in half their dependent FMAs.  No denormal / inf
+// special-casing: operands here are pivots, norms and step denominators.  Plain division on the host.
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(OD_EXACT_RCP)
 OD_HD double od_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);   // two steps measurably stall ill-conditioned solves on gfx950
-  return r;
+  const double r = __builtin_amdgcn_rcp(x);
+  const double e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, __builtin_fma(e, e, e), r);
 }
 OD_HD float od_rcp(float x) {
   float r = __builtin_amdgcn_rcpf(x);
@@ -115,9 +115,11 @@ OD_HD float od_rcp(float x) { return 1.0f / x; }
 // reciprocal square root (seed + Newton steps on the device)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(OD_EXACT_RCP)
 OD_HD double od_rsqrt(double x) {
+  // v_rsq_f64 seed: 24 bits; two Newton steps: < 1 ulp (a third changes the last bit on 11 % of operands, not the bound)
   double y = __builtin_amdgcn_rsq(x);
+  const double nhx = -0.5 * x;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) y = __builtin_fma(__builtin_fma(-0.5 * x * y, y, 0.5), y, y);
+  for (int i = 0; i < 2; ++i) y = __builtin_fma(__builtin_fma(nhx * y, y, 0.5), y, y);
   return y;
 }
 OD_HD float od_rsqrt(float x) {
