@@ -88,6 +88,10 @@ struct RowEmu {
   template <int W, class View_> static void store(const View_& v, const I& idx, long k, const V& x) {
     for (int i = 0; i < 8; ++i) { const int j = (idx.v[i] >> (8 * W)) & 0xFF; if (j != 0xFF) v.at(j, k) = x.v[i]; }
   }
+  static V vmax(const V& a, const V& b) { return od_fmax(a, b); }
+  static V vmin(const V& a, const V& b) { return od_fmin(a, b); }
+  static double vmax(double a, double b) { return od_fmax(a, b); }
+  static double vmin(double a, double b) { return od_fmin(a, b); }
   static bool first_lane() { return true; }
   static void arrived(const double&) {}
 };
@@ -145,6 +149,9 @@ struct RowDev {
     const int i = (idx >> (8 * W)) & 0xFF;
     if (lane() < 8 && i != 0xFF) v.at(i, k) = x;
   }
+  // max / min of values that came out of lane moves: the bare instruction (od_fmax would re-quiet both operands first)
+  __device__ __forceinline__ static double vmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+  __device__ __forceinline__ static double vmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
   __device__ __forceinline__ static bool first_lane() { return lane() == 0; }
   // the value of an earlier load is needed from here on (places the s_waitcnt)
   __device__ __forceinline__ static void arrived(const double& x) { asm volatile("" ::"v"(x)); }
@@ -170,6 +177,7 @@ template <class CM, class RO> struct CoopLanes {
   V jfc[CM::NQ];          // constant entries of the lane's aux-row Jacobian (slack row | velocity row) w.r.t. q
   V c_s, c_v, c_psi;      // r1 = e1 + c_s*D0 + c_v*D1 (c_v = d(velocity row)/d s_b = +-1 on cone lanes) ;  r2 = c_psi*P0 + gcoef*gamma_partner + gconst
   V gcoef, gconst;        // psi row: d/d gamma_partner, theta-only constant (set per knot)
+  V reg_floor;            // 0 on contact lanes, -inf elsewhere (the regularisation floor applies to orthant members)
   typename RO::I zg_idx;  // rows of z the lane's (P0, P1, D0, D1) go to in the gradient hand-over
   OD_HD void init() {
     zg_idx = RO::lane_pack4(CM::IDX_P0, CM::IDX_P1, CM::IDX_D0, CM::IDX_D1);
@@ -185,6 +193,7 @@ template <class CM, class RO> struct CoopLanes {
     c_s = RO::sel(is_contact, 1.0, 0.0);
     c_v = RO::lane_table(CM::CV);
     c_psi = RO::sel(is_cone, 1.0, 0.0);
+    reg_floor = RO::sel(is_contact, 0.0, -__builtin_inf());
     gcoef = V(0.0);
     gconst = V(0.0);
   }
@@ -247,15 +256,15 @@ template <class RO> OD_HD typename RO::V half_sum(typename RO::V v) {
   return v;
 }
 template <class RO> OD_HD typename RO::V half_max(typename RO::V v) {
-  v = od_fmax(v, RO::xor1(v));
-  v = od_fmax(v, RO::xor2(v));
-  v = od_fmax(v, RO::half_mirror(v));
+  v = RO::vmax(v, RO::xor1(v));
+  v = RO::vmax(v, RO::xor2(v));
+  v = RO::vmax(v, RO::half_mirror(v));
   return v;
 }
 template <class RO> OD_HD typename RO::V half_min(typename RO::V v) {
-  v = od_fmin(v, RO::xor1(v));
-  v = od_fmin(v, RO::xor2(v));
-  v = od_fmin(v, RO::half_mirror(v));
+  v = RO::vmin(v, RO::xor1(v));
+  v = RO::vmin(v, RO::xor2(v));
+  v = RO::vmin(v, RO::half_mirror(v));
   return v;
 }
 
@@ -311,7 +320,7 @@ OD_HD void coop_viol(const CoopLanes<CM, RO>& L, const CoopRes<CM::NQ, typename 
   double de, dk;
   RO::template bc2<0, 8>(v, de, dk);
   const double nan = __builtin_nan("");
-  de = od_fmax(de, ve);
+  de = RO::vmax(de, ve);
   r_vio = (se != se || de == inf) ? nan : de;
   k_vio = (dk == inf) ? nan : dk;
 }
@@ -328,8 +337,8 @@ OD_HD bool coop_eval_factor(const CoopLanes<CM, RO>& L, const CoopVec<CM::NQ, ty
   using V = typename RO::V;
   constexpr int NQ = CM::NQ;
   // orthant members clamped from below at reg (rz!(...; reg)); cone members are not
-  const V regl = RO::sel(L.is_contact, reg, -__builtin_inf());
-  const V P0c = od_fmax(z.P0, regl), D0c = od_fmax(z.D0, regl);
+  const V regl = L.reg_floor + reg;            // reg on contact lanes, -inf elsewhere
+  const V P0c = RO::vmax(z.P0, regl), D0c = RO::vmax(z.D0, regl);
   double zr[M::NZ], a[M::NNZ];
 #pragma unroll
   for (int i = 0; i < M::NZ; ++i) zr[i] = 0.0;
@@ -353,31 +362,31 @@ OD_HD bool coop_eval_factor(const CoopLanes<CM, RO>& L, const CoopVec<CM::NQ, ty
   if constexpr (CM::NK > 0) {
     f.gA = -(z.D0 * L.gcoef);
     f.gB = -(z.D1 * L.gcoef);
-    V qA[NQ], qB[NQ];
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-      // s_b eliminated through its velocity row (c_v d s_b + JF . dq = r_v, c_v = +-1): d s_b = c_v (r_v - JF . dq)
-      const V nJ = -(L.c_v * f.JF[j]);
-      qA[j] = CM::UPV[j] ? z.P1 * nJ : V(0.0);
-      qB[j] = CM::UPV[j] ? z.P0 * nJ : V(0.0);
-      if constexpr (CM::SH > 0) {
-        if (CM::UPJ[j]) {
-          const V tp = RO::template shr<CM::SH>(f.t[j]);
-          qA[j] = qA[j] + f.gA * tp;
-          qB[j] = qB[j] + f.gB * tp;
-        }
-      }
-    }
     // role swap (gen/<model>.h: sw = |psi| > |s_psi|): the first pivot row is the head row A (on s_psi) if sw, the tail
-    // row B (on b) otherwise.  The rows are exchanged physically and the second row is reduced entry by entry, in the
-    // order of the lane-per-problem elimination.  (Folding the exchange into scalar coefficients, W = cA qA + cB qB,
-    // saves selects but subtracts two large products when the second pivot is small; a build with that form and with
+    // row B (on b) otherwise.  The rows are exchanged physically -- through the four coefficients they are built from,
+    // row A = P1 nJ + gA t', row B = P0 nJ + gB t' -- and the second row is reduced entry by entry, in the order of the
+    // lane-per-problem elimination.  (Folding the exchange into scalar coefficients of the finished rows,
+    // W = cA qA + cB qB, subtracts two large products when the second pivot is small; a build with that form and with
     // multiplicative role masks stopped converging on the device -- not bisected further, this is the stable form.)
     f.sw = od_abs(z.P0) > od_abs(z.D0);
     const V p1 = RO::sel(f.sw, z.P0, z.D0), o2 = RO::sel(f.sw, z.P1, z.D1), p2 = RO::sel(f.sw, z.D0, z.P0);
     f.o1 = RO::sel(f.sw, z.D1, z.P1);
+    const V m1 = RO::sel(f.sw, z.P1, z.P0), m2 = RO::sel(f.sw, z.P0, z.P1);
+    const V g1 = RO::sel(f.sw, f.gA, f.gB), g2 = RO::sel(f.sw, f.gB, f.gA);
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) { f.q1[j] = RO::sel(f.sw, qA[j], qB[j]); f.q2[j] = RO::sel(f.sw, qB[j], qA[j]); }
+    for (int j = 0; j < NQ; ++j) {
+      // s_b eliminated through its velocity row (c_v d s_b + JF . dq = r_v, c_v = +-1): d s_b = c_v (r_v - JF . dq)
+      const V nJ = -(L.c_v * f.JF[j]);
+      f.q1[j] = CM::UPV[j] ? m1 * nJ : V(0.0);
+      f.q2[j] = CM::UPV[j] ? m2 * nJ : V(0.0);
+      if constexpr (CM::SH > 0) {
+        if (CM::UPJ[j]) {
+          const V tp = RO::template shr<CM::SH>(f.t[j]);
+          f.q1[j] = f.q1[j] + g1 * tp;
+          f.q2[j] = f.q2[j] + g2 * tp;
+        }
+      }
+    }
     f.ip1 = od_rcp(p1);
     f.l2 = o2 * f.ip1;
     const V p2e = p2 - f.l2 * f.o1;
@@ -454,7 +463,7 @@ OD_HD void coop_solve(const CoopLanes<CM, RO>& L, const CoopFact<CM, RO>& f, con
     // arithmetic of a contact lane may overflow when gamma or s underflow, and 0 * inf would poison its rows)
     x.P1 = RO::sel(L.is_cone, db, 0.0);
     x.D0 = RO::sel(L.is_cone, dsp, a1);
-    x.D1 = RO::sel(L.is_cone, L.c_v * a1, 0.0);
+    x.D1 = L.c_v * a1;                          // c_v is 0 off the cone lanes, a1 their finite slack direction
   } else {
     x.P0 = dg; x.P1 = V(0.0); x.D0 = a1; x.D1 = V(0.0);
   }
@@ -493,7 +502,7 @@ OD_HD StepPre<RO> coop_step_pre(const CoopLanes<CM, RO>& L, const CoopVec<CM::NQ
   return p;
 }
 
-template <class RO> OD_HD typename RO::V coop_soc_step2(const StepPre<RO>& p, typename RO::V d0, typename RO::V d1, double tau) {
+template <class RO> OD_HD typename RO::V coop_soc_step2(const StepPre<RO>& p, typename RO::V d0, typename RO::V d1, double tau, typename RO::V& den) {
   using V = typename RO::V;
   V ld = p.l0 * d0;
   ld = ld - p.l1 * d1;
@@ -501,8 +510,8 @@ template <class RO> OD_HD typename RO::V coop_soc_step2(const StepPre<RO>& p, ty
   const V rs = ld * p.ill;
   const V c = (ld * p.isq + d0) * p.rc1;
   const V nv = od_abs(d1 * p.isq - c * p.l1 * p.ill);
-  const V den = nv - rs;
-  return RO::sel(den > 0.0, tau * od_rcp(den), 1.0);      // the caller caps at 1
+  den = nv - rs;
+  return tau * od_rcp(den);                                // where den > 0; the caller caps at 1
 }
 
 template <class CM, class RO>
@@ -513,18 +522,19 @@ OD_HD double coop_step_length(const CoopLanes<CM, RO>& L, const StepPre<RO>& p, 
   const V d0h = RO::sel(L.half, d.D0, d.P0);
   if constexpr (CM::NC > 0) {
     // lanes 0..7 test gamma, their mirrors test s:  alpha <= tau * z / d  where d > 0
-    const V ao = RO::sel(d0h > 0.0, (tau_ort * p.zz) * od_rcp(d0h), 1.0);
-    a = RO::sel(L.is_contact, ao, a);
+    a = RO::sel(L.is_contact && (d0h > 0.0), (tau_ort * p.zz) * od_rcp(d0h), a);
   }
   if constexpr (CM::NK > 0) {
     const V d1h = RO::sel(L.half, d.D1, d.P1);
-    a = RO::sel(L.is_cone, coop_soc_step2<RO>(p, -d0h, -d1h, tau_soc), a);
+    V den;
+    const V as = coop_soc_step2<RO>(p, -d0h, -d1h, tau_soc, den);
+    a = RO::sel(L.is_cone && (den > 0.0), as, a);
   }
   a = od_fmin(a, V(1.0));
   a = half_min<RO>(a);
   double a0, a1;
   RO::template bc2<0, 8>(a, a0, a1);
-  return od_fmin(a0, a1);
+  return RO::vmin(a0, a1);
 }
 
 // CVXOPT sec. 5.1.3: mu = <primal, dual>/ncones ; sigma = clamp(mu_aff/mu, 0, 1)^3  (od_solver.h::centering_kappa)
@@ -574,7 +584,7 @@ OD_HD void coop_iteration(const CoopLanes<CM, RO>& L, const Opts<double>& o, con
     r.rB = r.rB + (D.P0 * D.D1 + D.P1 * D.D0);
     coop_solve<CM, PIV, RO>(L, f, z, r, D);
   }
-  const double vio = od_fmax(r_vio, k_vio);
+  const double vio = RO::vmax(r_vio, k_vio);
   const double tau = 1.0 - od_fmin(o.eps_min, vio * vio);
   double alpha = coop_step_length<CM, RO>(L, sp, D, tau, od_fmin(tau, 0.99));
   // backtracking until either violation does not increase (od_solver.h::line_search, sequential form)
