@@ -37,6 +37,12 @@ out.append("k_rollout_state: %d wavefronts, %.2f M VALU instructions per wavefro
            % (s["SQ_WAVES"], s["SQ_INSTS_VALU"] / s["SQ_WAVES"] / 1e6, s["SQ_WAVE_CYCLES"] / s["SQ_INSTS_VALU"],
               100 * s["SQ_ACTIVE_INST_VALU"] / s["SQ_WAVE_CYCLES"], 100 * s["SQ_WAIT_ANY"] / s["SQ_WAVE_CYCLES"],
               100 * s["SQ_WAIT_INST_ANY"] / s["SQ_WAVE_CYCLES"]))
+if os.path.exists(os.path.join(src, "pmc_sq2", "p_counter_collection.csv")):
+    m2, _ = per_kernel("pmc_sq2")
+    s2 = m2["k_rollout_state"]
+    out.append("k_rollout_state, second SQ pass per dispatch: %s" % json.dumps({c: int(v) for c, v in sorted(s2.items())}))
+    out.append("k_rollout_state: scalar instructions %.0f %% of wave cycles (a lone wavefront per SIMD issues them in its own time), s_nop and other MISC %.1f %%, %.0f K vector memory instructions per dispatch"
+               % (100 * s2["SQ_ACTIVE_INST_SCA"] / s["SQ_WAVE_CYCLES"], 100 * s2["SQ_ACTIVE_INST_MISC"] / s["SQ_WAVE_CYCLES"], s2["SQ_INSTS_VMEM"] / 1e3))
 sys.path.insert(0, ROOT)
 import bench
 json.dump({"tag": tag, "workload": "bench.py default (hopper T=100 batch=4096, od_rollout_compact)", "hbm_bytes_per_step": tot,
