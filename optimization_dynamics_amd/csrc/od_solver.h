@@ -94,6 +94,7 @@ template <class M, int C, class T> OD_HD T soc_step_cone(const T* z, const T* D,
 // ---- lane cooperation between the copies of one problem (Opts::coop) --------------------------------
 // Lanes 0..15 of a wavefront are one DPP row; the copies of a problem sit ppw lanes apart, so rotating
 // the row by ppw and 2*ppw reaches four of them.
+#if defined(__HIP_DEVICE_COMPILE__) || defined(OD_HOST_EMU_LOCKSTEP)
 #if defined(__HIP_DEVICE_COMPILE__)
 template <int R> __device__ __forceinline__ double od_row_ror(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -104,24 +105,29 @@ template <int R> __device__ __forceinline__ double od_row_ror(double v) {
 template <int R> __device__ __forceinline__ float od_row_ror(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x120 + R, 0xF, 0xF, false));
 }
-template <class T> __device__ __forceinline__ T coop_min4(T v, int ppw) {
+template <int R> __device__ __forceinline__ int od_row_ror(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x120 + R, 0xF, 0xF, false); }
+#else   // host test build with lockstep rows (tests/host_emu/hip/hip_runtime.h): the same rotations between host threads
+template <int R> inline double od_row_ror(double v) { uint64_t b; __builtin_memcpy(&b, &v, 8); b = od_emu_row_ror_bits(b, R); __builtin_memcpy(&v, &b, 8); return v; }
+template <int R> inline float od_row_ror(float v) { uint32_t b; __builtin_memcpy(&b, &v, 4); b = (uint32_t)od_emu_row_ror_bits(b, R); __builtin_memcpy(&v, &b, 4); return v; }
+template <int R> inline int od_row_ror(int v) { return (int)(uint32_t)od_emu_row_ror_bits((uint32_t)v, R); }
+#endif
+template <class T> OD_HD T coop_min4(T v, int ppw) {
   if (ppw == 4) { v = od_min(v, od_row_ror<4>(v)); v = od_min(v, od_row_ror<8>(v)); }
   else if (ppw == 2) { v = od_min(v, od_row_ror<2>(v)); v = od_min(v, od_row_ror<4>(v)); }
   else { v = od_min(v, od_row_ror<1>(v)); v = od_min(v, od_row_ror<2>(v)); }
   return v;
 }
-__device__ __forceinline__ int coop_group(int ppw) { return (((int)threadIdx.x & 63) / ppw) & 3; }
-template <int R> __device__ __forceinline__ int od_row_ror(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x120 + R, 0xF, 0xF, false); }
+OD_HD int coop_group(int ppw) { return (((int)threadIdx.x & 63) / ppw) & 3; }
 // bitwise OR over ALL 16/ppw copies of a problem, and the index of a lane among them
-__device__ __forceinline__ int coop_or_all(int v, int ppw) {
+OD_HD int coop_or_all(int v, int ppw) {
   if (ppw <= 1) v |= od_row_ror<1>(v);
   if (ppw <= 2) v |= od_row_ror<2>(v);
   v |= od_row_ror<4>(v);
   v |= od_row_ror<8>(v);
   return v;
 }
-__device__ __forceinline__ int coop_copy(int ppw) { return ((int)threadIdx.x & 15) / ppw; }
-#else   // the host test build runs lanes one after the other: no cooperation
+OD_HD int coop_copy(int ppw) { return ((int)threadIdx.x & 15) / ppw; }
+#else   // host builds without lockstep rows: lanes run one after the other, no cooperation (Opts::coop = 0)
 template <class T> OD_HD T coop_min4(T v, int) { return v; }
 OD_HD int coop_group(int) { return 0; }
 OD_HD int coop_or_all(int v, int) { return v; }

@@ -1,6 +1,9 @@
 #include <hip/hip_runtime.h>
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 int od_trace_flag = 0;
+int od_emu_lockstep = 0;
+thread_local OdEmuRowBus* od_emu_bus = nullptr;
+extern "C" void od_emu_set_lockstep(int v) { od_emu_lockstep = v; }
 extern "C" void od_emu_set_trace(int v) { od_trace_flag = v; }
 thread_local double od_lds[160 * 1024 / 8];   // emulated per-workgroup LDS (one workgroup per OpenMP thread at a time)
 

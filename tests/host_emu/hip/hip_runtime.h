@@ -4,8 +4,13 @@
 // can be checked against the oracle in the CPU-only test tier; it is built only by
 // tests/host_emu/Makefile into tests/host_emu/libod_emu.so and is never loaded by the product.
 #pragma once
+#include <condition_variable>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
 
 #define __global__
 #define __device__
@@ -33,10 +38,74 @@ inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 
+// ---- lockstep rows (od_emu_set_lockstep(1)): the 16 threads of a DPP row run as 16 host threads that meet at every
+// cross-lane operation, so the lane cooperation of od_solver.h (row rotations between the copies of a problem: shared
+// step-length tests, parallel line search) executes in the CPU test tier exactly as written for the device.
+struct OdEmuRowBus {
+  std::mutex m;
+  std::condition_variable cv;
+  int n = 0, waiting = 0;
+  unsigned long gen = 0;
+  uint64_t slot[16];
+  bool present[16];
+  void barrier_locked(std::unique_lock<std::mutex>& lk) {
+    const unsigned long g = gen;
+    if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); }
+    else cv.wait(lk, [&] { return gen != g; });
+  }
+  // lane `lane` contributes v and receives the contribution of lane `src`; a lane that has left the kernel reads as
+  // the receiver's own value (the device's DPP `old` operand under an inactive source lane)
+  uint64_t exchange(int lane, int src, uint64_t v) {
+    std::unique_lock<std::mutex> lk(m);
+    slot[lane] = v;
+    barrier_locked(lk);
+    const uint64_t r = present[src] ? slot[src] : v;
+    barrier_locked(lk);
+    return r;
+  }
+  void leave(int lane) {
+    std::unique_lock<std::mutex> lk(m);
+    present[lane] = false;
+    --n;
+    if (n > 0 && waiting == n) { waiting = 0; ++gen; cv.notify_all(); }
+  }
+};
+extern int od_emu_lockstep;
+extern thread_local OdEmuRowBus* od_emu_bus;
+#define OD_HOST_EMU_LOCKSTEP 1
+// row_ror:R -- lane l receives lane (l + 16 - R) % 16 of its row (identity when rows do not run in lockstep)
+inline uint64_t od_emu_row_ror_bits(uint64_t v, int R) {
+  if (!od_emu_bus) return v;
+  const int lane = (int)(threadIdx.x & 15);
+  return od_emu_bus->exchange(lane, (lane + 16 - R) & 15, v);
+}
+
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                 \
   do {                                                                              \
     dim3 g_ = (grid), b_ = (block);                                                 \
     gridDim = g_; blockDim = b_;                                                    \
+    if (od_emu_lockstep) {                                                          \
+      for (long bx_ = 0; bx_ < (long)g_.x; ++bx_) {                                 \
+        for (unsigned r0_ = 0; r0_ < b_.x; r0_ += 16) {                             \
+          OdEmuRowBus bus_;                                                         \
+          const unsigned nl_ = b_.x - r0_ < 16 ? b_.x - r0_ : 16;                   \
+          bus_.n = (int)nl_;                                                        \
+          for (unsigned l_ = 0; l_ < 16; ++l_) bus_.present[l_] = l_ < nl_;         \
+          std::vector<std::thread> ts_;                                             \
+          for (unsigned l_ = 0; l_ < nl_; ++l_)                                     \
+            ts_.emplace_back([&, l_]() {                                            \
+              gridDim = g_; blockDim = b_;                                          \
+              blockIdx = dim3((unsigned)bx_); threadIdx = dim3(r0_ + l_);           \
+              od_emu_bus = &bus_;                                                   \
+              kernel(__VA_ARGS__);                                                  \
+              od_emu_bus = nullptr;                                                 \
+              bus_.leave((int)l_);                                                  \
+            });                                                                     \
+          for (auto& t_ : ts_) t_.join();                                           \
+        }                                                                           \
+      }                                                                             \
+      break;                                                                        \
+    }                                                                               \
     _Pragma("omp parallel for schedule(dynamic, 1)")                                \
     for (long bx_ = 0; bx_ < (long)g_.x; ++bx_) {                                   \
       gridDim = g_; blockDim = b_;                                                  \

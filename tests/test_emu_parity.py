@@ -231,3 +231,36 @@ def test_tail_lu_against_numpy(emu_lib):
 
 def test_rollout_with_finite_undercut(oracle, emu_lib):
     P.check_rollout_finite_undercut(oracle, emu_lib, "cpu")
+
+
+@pytest.mark.parametrize("name", ["acrobot_impact", "hopper", "cartpole_friction", "planar_push"])
+def test_lane_cooperation_in_lockstep_rows(emu_lib, name):
+    """The lane cooperation of the lane-per-problem kernels (od_solver.h: cone / orthant step-length tests shared out
+    over the 16/ppw copies of a problem, parallel line search; DPP row rotations on the device) on the CPU: the host
+    build runs the 16 threads of a row as 16 host threads that meet at every rotation (tests/host_emu/hip/hip_runtime.h),
+    and every mapping must give what the sequential build gives -- states, status and iteration counts bit for bit."""
+    B = 21 if name == "planar_push" else 45                          # ragged: the last row carries fewer problems
+    X, U = W.knots(name, 4099 if name == "acrobot_impact" else 8 * B, seed=17)
+    if name == "acrobot_impact":                                       # keep the knots that jam (cooperative backtracking)
+        im0 = P.make_im(name, emu_lib, "cpu")
+        it0 = im0.step_grad(torch.tensor(X), torch.tensor(U))[4][0].numpy()
+        order = np.argsort(-it0)
+        X, U = np.ascontiguousarray(X[:, order[:B]]), np.ascontiguousarray(U[:, order[:B]])
+        assert it0[order[0]] > 20
+    else:
+        X, U = np.ascontiguousarray(X[:, :B]), np.ascontiguousarray(U[:, :B])
+    im = P.make_im(name, emu_lib, "cpu")
+    im.set_cooperative(1)
+    im.set_launch_config(16, 4)
+    ref = [t.clone() for t in im.step_grad(torch.tensor(X), torch.tensor(U))]
+    emu_lib.cdll.od_emu_set_lockstep(1)
+    try:
+        for ppw, wpb in [(1, 4), (2, 4), (4, 1)]:
+            im.set_launch_config(ppw, wpb)
+            cur = im.step_grad(torch.tensor(X), torch.tensor(U))
+            assert torch.equal(ref[3], cur[3]) and torch.equal(ref[4], cur[4]), ppw
+            assert torch.equal(ref[0], cur[0]), ppw
+            ok = ((cur[3] & 3) == 3).numpy()
+            P.assert_grad_close(np.concatenate([ref[1].numpy(), ref[2].numpy()], 1), np.concatenate([cur[1].numpy(), cur[2].numpy()], 1), ok, "ppw %d" % ppw)
+    finally:
+        emu_lib.cdll.od_emu_set_lockstep(0)
