@@ -53,4 +53,12 @@ if os.path.exists(notes):
     out.append("")
     out.append(open(notes).read().rstrip())
 open(os.path.join(dst, tag + "_pmc_summary.txt"), "w").write("\n".join(out) + "\n")
+# the bench line of this profile run was printed before its own PMC passes existed: give it their traffic figure
+# (same sources, same command), as bench.py does on every later run through profiles/<tag>_traffic.json
+line = json.load(open(os.path.join(src, "bench.json")))
+if line["roofline"].get("traffic") is None:
+    line["roofline"]["traffic"] = tot
+    line["roofline"]["traffic_note"] = "profiles/%s_traffic.json: the PMC passes of this same profile run (tools/profile_round.sh); algorithmic = %d" % (
+        tag, int(line["roofline"]["hbm_algorithmic_GBps"] * 1e9 * line["ms_per_step"] * 1e-3 + 0.5))
+json.dump(line, open(os.path.join(dst, tag + "_bench.json"), "w"))
 print("\n".join(out))
