@@ -59,6 +59,6 @@ line = json.load(open(os.path.join(src, "bench.json")))
 if line["roofline"].get("traffic") is None:
     line["roofline"]["traffic"] = tot
     line["roofline"]["traffic_note"] = "profiles/%s_traffic.json: the PMC passes of this same profile run (tools/profile_round.sh); algorithmic = %d" % (
-        tag, int(line["roofline"]["hbm_algorithmic_GBps"] * 1e9 * line["ms_per_step"] * 1e-3 + 0.5))
+        tag, int(line["roofline"]["traffic_note"].rsplit("algorithmic = ", 1)[1]))
 json.dump(line, open(os.path.join(dst, tag + "_bench.json"), "w"))
 print("\n".join(out))
