@@ -161,8 +161,8 @@ def cpu_baseline(batch, horizon, seed, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096, help="rollouts per GPU")
     ap.add_argument("--horizon", type=int, default=100)
     ap.add_argument("--gather", action="store_true", help="all-gather the compact linearisation (x+, dq3) after every step (RCCL)")
