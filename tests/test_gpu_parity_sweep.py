@@ -1,7 +1,7 @@
 """Larger parity sweep on the GPU (-m gpu): every mechanical model, several seeds, thousands of knots against the CPU
 oracle (OpenMP over the batch) and, for the implicit gradients, against the binary128 arbiter (oracle/arbiter.c) at
 the device's own and at the oracle's own gradient iterates.  The 1e-6 / 1e-4 bars are asserted on 100 % of the
-converged knots; both gradient error columns go to gpurun_out/parity_sweep.json (copied to profiles/ for the round)."""
+converged knots whose solution the oracle itself reproduces under 1e-13 input perturbations (all but ~2 per million); both gradient error columns go to gpurun_out/parity_sweep.json (copied to profiles/ for the round)."""
 import json
 import os
 
@@ -18,12 +18,16 @@ MECH = ["acrobot_impact", "acrobot_nominal", "cartpole_friction", "cartpole_fric
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# OD_SWEEP_SEEDS=1,2,3,... widens the sweep (a soak run for profiles/; the default three seeds are the test)
+SEEDS = tuple(int(t) for t in os.environ.get("OD_SWEEP_SEEDS", "101,202,303").split(","))
+
+
 def test_parity_sweep(oracle, gpu_lib):
     out = {}
     for name in MECH:
         B = 2048 if name == "planar_push" else 8192
         rows = []
-        for seed in (101, 202, 303):
+        for seed in SEEDS:
             X, U = W.knots(name, B, seed=seed)
             im = P.make_im(name, gpu_lib, DEV)
             D, DX, DU, st, it = [t.cpu().numpy() for t in im.step_grad(torch.tensor(X), torch.tensor(U))]
@@ -37,13 +41,26 @@ def test_parity_sweep(oracle, gpu_lib):
             assert not (nan_dev & ok & ~nan_ora).any()
             assert (nan_ora & ok).sum() <= 2
             ok = ok & ~nan_ora
-            srel = (np.abs(D - Do).max(0) / np.maximum(1e-2, np.abs(Do).max(0)))[ok]
+            srel_all = np.abs(D - Do).max(0) / np.maximum(1e-2, np.abs(Do).max(0))
+            # A state mismatch is a failure unless the ORACLE ITSELF does not reproduce its answer there: the knot is
+            # solved again by the oracle from inputs perturbed by 1e-13 relative (16 draws).  Newton / interior-point
+            # paths of 20-70 iterations through several contact modes end on different roots under such perturbations
+            # (seen on 2 of 1.2 million knots, profiles/r2_parity_soak.json); no implementation can be compared there.
+            path_dependent = np.zeros(B, bool)
+            for i in np.nonzero(ok & (srel_all >= P.STATE_TOL))[0]:
+                rng = np.random.default_rng(int(i))
+                Xp = X[:, [i]] * (1 + 1e-13 * rng.normal(size=(X.shape[0], 16)))
+                Up = U[:, [i]] * (1 + 1e-13 * rng.normal(size=(U.shape[0], 16)))
+                Dp = oracle.step_grad_batch(P.make_sim(oracle, name), Xp, Up)[0]
+                path_dependent[i] = (np.ptp(Dp, axis=1).max() / max(1e-2, np.abs(Do[:, i]).max())) > 10 * P.STATE_TOL
+            ok = ok & ~path_dependent
+            srel = srel_all[ok]
             grel = W.grad_rel_err(np.concatenate([DX, DU], 1), np.concatenate([DXo, DUo], 1))[ok]
             nq = X.shape[0] // 2
             e = P.exact_gradient_errors(oracle, im, name, X, U, np.concatenate([DX[nq:], DU[nq:]], 1))
             fin = ok & np.isfinite(e["dev"]) & np.isfinite(e["explained"])
             excess = e["cross"][fin] - 2.0 * e["explained"][fin]
-            rows.append(dict(seed=seed, knots=B, converged=int(ok.sum()), oracle_nonconverged_solves=int(bad), oracle_singular=int(nan_ora.sum()),
+            rows.append(dict(seed=seed, knots=B, converged=int(ok.sum()), path_dependent_knots=int(path_dependent.sum()), oracle_nonconverged_solves=int(bad), oracle_singular=int(nan_ora.sum()),
                              state_rel_max=float(srel.max()), state_rel_median=float(np.median(srel)),
                              grad_rel_median=float(np.median(grel)), grad_rel_p99=float(np.percentile(grel, 99)),
                              grad_rel_p999=float(np.percentile(grel, 99.9)), grad_rel_max=float(grel.max()),
@@ -64,6 +81,7 @@ def test_parity_sweep(oracle, gpu_lib):
     for name, rows in out.items():
         for r in rows:
             assert r["converged"] > 0.99 * r["knots"], (name, r)
+            assert r["path_dependent_knots"] <= 2, (name, r)
             assert r["state_rel_max"] < P.STATE_TOL, (name, r)                       # 1e-6 relative on states
             # implicit gradients, 100 % of the converged knots: the device reproduces the exact (binary128) gradient at its
             # own iterate, and differs from the oracle by no more than 1e-4 beyond what the two iterates explain
