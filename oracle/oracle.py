@@ -256,6 +256,25 @@ def arbiter_dq3(sim, X, U, Zg):
     return G.reshape(nq, 2 * nq + nu, B, order="F"), cond
 
 
+def arbiter_dz(sim, x, u, zg):
+    """EXTENDED-PRECISION ARBITER, one knot, the whole solution: dz/d theta (nz, ntheta) = -rz(z; reg)^{-1} rtheta(z) at
+    the iterate zg (nz+1: z and, last, the clamp), theta built from (x, u) as the step does; + cond"""
+    d = dims(sim.model_id)
+    nq, nu, nz, nth, nf = d["nq"], d["nu"], d["nz"], d["nth"], d["nfric"]
+    x = np.asarray(x, dtype=np.float64); u = np.asarray(u, dtype=np.float64); zg = np.ascontiguousarray(zg, dtype=np.float64)
+    th = np.zeros(nth)
+    v1 = (x[nq:] - x[:nq]) / sim.h
+    th[:nq] = x[nq:] - sim.h * v1
+    th[nq:2 * nq] = x[nq:]
+    th[2 * nq:2 * nq + nu] = u
+    th[2 * nq + nu:2 * nq + nu + nf] = [sim.fric[i] for i in range(nf)]
+    th[2 * nq + nu + nf] = sim.h
+    dz = np.zeros(nz * nth)
+    cond = C.c_double()
+    lib().od_arbiter_gradient(sim.model_id, _p(zg[:nz].copy()), _p(th), C.c_double(float(zg[nz])), _p(dz), C.byref(cond))
+    return dz.reshape(nz, nth, order="F"), cond.value
+
+
 def rollout(sim, x1, U, grads=True, bufs=None):
     """x1: (2nq,B); U: (nu,T,B) -> X (2nq,T+1,B), A (2nq,2nq,T,B), Bm (2nq,nu,T,B), nbad.
     `bufs` (a dict, filled on first use) lets a caller time the solves without the page faults of fresh output arrays."""
