@@ -158,7 +158,9 @@ int od_ilqr_backward(od_handle h, long B, int T, int n, int m, const void* A, co
 /* gradient! (src/gradient_bundle.jl:87-104) for B knots: N+1 eval-simulator steps per knot with the
  * caller's perturbations eta ((2nq+nu) x N col-major, shared by all knots; the reference draws them
  * in the GradientBundle constructor :49-54) followed by the least-squares fit of src/ls.jl:44-60.
- * dz: nq x (2nq+nu) per knot.  workspace: device scratch of od_bundle_workspace_bytes(). */
+ * dz: nq x (2nq+nu) per knot.  workspace: device scratch of od_bundle_workspace_bytes().
+ * status (per knot): 1 = the Gram matrix of the perturbations is non-singular and the fit is finite (a sample whose
+ * solve failed with a non-finite state makes it 0; non-converged but finite samples enter the fit as in the reference). */
 size_t od_bundle_workspace_bytes(od_handle h, long B, int N);
 int od_bundle_grad(od_handle h, long B, int N, const void* x, const void* u, const void* eta,
                    void* dz, void* workspace, size_t workspace_bytes, int* status);
@@ -166,7 +168,7 @@ int od_bundle_grad(od_handle h, long B, int N, const void* x, const void* u, con
 /* LeastSquares update! (src/ls.jl:44-60) alone, for B independent fits: minimise
  * sum_i |f_eta_i - f_z - M eta_i|^2 over M (ny x nzb).  feta: ny per sample, (N+1)*B samples in
  * BATCH_MINOR order, sample index b*(N+1)+i with i = 0 the unperturbed f_z; eta: nzb x N col-major;
- * M: ny x nzb per fit (handle layout).  ny, nzb <= 24. */
+ * M: ny x nzb per fit (handle layout).  ny, nzb <= 24.  status as for od_bundle_grad. */
 int od_ls_fit(od_handle h, long B, int N, int ny, int nzb, const void* eta, const void* feta, void* M,
               int* status);
 

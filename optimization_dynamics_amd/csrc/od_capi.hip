@@ -99,6 +99,7 @@ __global__ __launch_bounds__(OD_BLOCK) void k_ls_solve(long B, int ny, int nzb, 
   const double* g = acc + b * ne;
   for (int i = 0; i < nzb * nzb; ++i) A[i] = g[i];
   bool ok = true;
+  double chk = 0.0;
   for (int k = 0; k < nzb; ++k) {
     int p = k;
     double best = fabs(A[k + nzb * k]);
@@ -115,9 +116,9 @@ __global__ __launch_bounds__(OD_BLOCK) void k_ls_solve(long B, int ny, int nzb, 
     for (int k = 0; k < nzb; ++k) { const int p = piv[k]; if (p != k) { const double t = x[k]; x[k] = x[p]; x[p] = t; } }
     for (int k = 0; k < nzb; ++k) for (int i = k + 1; i < nzb; ++i) x[i] -= A[i + nzb * k] * x[k];
     for (int k = nzb - 1; k >= 0; --k) { x[k] /= A[k + nzb * k]; for (int i = 0; i < k; ++i) x[i] -= A[i + nzb * k] * x[k]; }
-    for (int c = 0; c < nzb; ++c) dz.at(a + ny * c, b) = x[c];
+    for (int c = 0; c < nzb; ++c) { dz.at(a + ny * c, b) = x[c]; chk += x[c] * 0.0; }
   }
-  if (status.ok()) status.at(0, b) = ok ? 1 : 0;
+  if (status.ok()) status.at(0, b) = (ok && chk == chk) ? 1 : 0;     // ... and the fit is finite (a sample may carry a failed solve's NaN)
 }
 
 
@@ -134,15 +135,16 @@ __global__ __launch_bounds__(OD_BLOCK) void k_ls_solve_fixed(long B, const doubl
 #pragma unroll
   for (int i = 0; i < NZB * NZB; ++i) A[i] = g[i];
   const bool ok = od_lu_factor<double, NZB>(A, piv);
+  double chk = 0.0;
 #pragma unroll
   for (int a = 0; a < NY; ++a) {               // G symmetric: row a of M solves G x = R(a,:)'
 #pragma unroll
     for (int c = 0; c < NZB; ++c) x[c] = g[NZB * NZB + c + NZB * a];
     od_lu_solve<double, NZB>(A, piv, x);
 #pragma unroll
-    for (int c = 0; c < NZB; ++c) dz.at(a + NY * c, b) = x[c];
+    for (int c = 0; c < NZB; ++c) { dz.at(a + NY * c, b) = x[c]; chk += x[c] * 0.0; }
   }
-  if (status.ok()) status.at(0, b) = ok ? 1 : 0;
+  if (status.ok()) status.at(0, b) = (ok && chk == chk) ? 1 : 0;
 }
 
 // ---- iLQR backward pass (Riccati recursion), one lane per trajectory; runtime sizes n <= 16, m <= 12 --------

