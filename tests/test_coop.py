@@ -142,11 +142,28 @@ def _edge_check(lib, device, name, kw):
     fin = np.isfinite(ref[0]).all(0) & np.isfinite(got[0]).all(0)
     # (iterating past the attainable precision ends some solves on a singular factor: non-finite in both kernels alike)
     assert (fin | ~same).all() or fin.mean() > (0.8 if noise_level else 0.95)
-    e = np.abs(ref[0] - got[0])[:, same & fin].max(0)
-    assert np.median(e) < 1e-12 and e.max() < (1e-4 if noise_level else 1e-6), (kw, np.median(e), e.max())
+    bound = 1e-4 if noise_level else 1e-6
+    e_all = np.abs(ref[0] - got[0]).max(0)
+    # a knot on which the two kernels land apart is a failure unless the lane-per-problem kernel does not reproduce
+    # ITSELF there: 16 copies of the knot with inputs perturbed by 1e-13 relative (several roots within reach of a long
+    # Newton path -- tests/parity_checks.py::comparable_states does the same with the oracle)
+    sel = same & fin
+    im = P.make_im(name, lib, device)
+    im.set_options(**kw)
+    im.set_cooperative(1)
+    for i in np.nonzero(sel & ~(e_all < bound))[0]:
+        rng = np.random.default_rng(int(i))
+        Xp = X[:, [i]] * (1 + 1e-13 * rng.normal(size=(X.shape[0], 16)))
+        Up = U[:, [i]] * (1 + 1e-13 * rng.normal(size=(U.shape[0], 16)))
+        Dp = im.step(torch.tensor(Xp, device=device), torch.tensor(Up, device=device))[0].cpu().numpy()
+        if np.ptp(Dp, axis=1).max() > 10 * bound:
+            sel[i] = False
+    assert (same & fin & ~sel).sum() <= 1
+    e = e_all[sel]
+    assert np.median(e) < 1e-12 and e.max() < bound, (kw, np.median(e), e.max())
     assert np.array_equal(np.isnan(ref[0]), np.isnan(got[0])) or same.mean() < 1.0
-    e5 = np.abs(ref[5] - got[5])[:, same & fin].max(0)
-    assert e5.max() < (1e-4 if noise_level else 1e-6), kw
+    e5 = np.abs(ref[5] - got[5])[:, sel].max(0)
+    assert e5.max() < bound, kw
 
 
 @pytest.mark.parametrize("kw", EDGE_OPTIONS, ids=lambda d: ",".join("%s=%g" % kv for kv in d.items()))
