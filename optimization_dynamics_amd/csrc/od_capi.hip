@@ -1019,6 +1019,8 @@ int od_soc_project(od_handle h, long B, const void* u, void* uproj, void* duproj
 static int host_call(od_handle h, const double* x, const double* u, double* d, double* dx, double* du) {
   if (int rc = check_mech(h, "od_f_host")) return rc;
   const int n = 2 * h->vt->nq, nu = h->vt->nu;
+  if (!x || (nu > 0 && !u)) return fail(OD_ERR_INVALID, "od_f_host / od_fx_host / od_fu_host: null x / u");
+  if (!d && !dx && !du) return fail(OD_ERR_INVALID, "od_f_host / od_fx_host / od_fu_host: no output buffer");
   const size_t need = (size_t)n + nu + n + (size_t)n * n + (size_t)n * nu;
   if (h->stage_elems < need) {
     if (h->stage) (void)hipFree(h->stage);

@@ -79,3 +79,59 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 for pat in ("from oracle", "import oracle", "libod_oracle", "oracle/", "od_oracle_"):
                     assert pat not in txt, (pat, os.path.join(dp, f))
+
+
+def _zero_args(fn, handle=None):
+    args = []
+    for i, t in enumerate(fn.argtypes or []):
+        if i == 0 and handle is not None and t is C.c_void_p:
+            args.append(handle)
+        elif t in (C.c_double,):
+            args.append(0.0)
+        elif t in (C.c_void_p, C.c_char_p) or hasattr(t, "contents") or "LP_" in getattr(t, "__name__", ""):
+            args.append(None)
+        else:
+            args.append(0)
+    return args
+
+
+def _null_fuzz(emu_lib, device):
+    from optimization_dynamics_amd import _lib
+    import parity_checks as P
+    cd = emu_lib.cdll
+    queries = {"od_version", "od_num_models", "od_model_name", "od_last_error", "od_model_indices", "od_model_dims",
+               "od_raw_grad_dims", "od_uses_cooperative", "od_bundle_workspace_bytes", "od_destroy"}
+    for name in sorted(_lib.SIGNATURES):
+        fn = getattr(cd, name)
+        r = fn(*_zero_args(fn))
+        if name not in queries:
+            assert r < 0, (name, r)
+    for model in ("hopper", "rocket_dynamics"):
+        if model == "hopper":
+            owner = P.make_im(model, emu_lib, device)
+        else:
+            from optimization_dynamics_amd import models, rocket as rk
+            owner = rk.RocketInfo(models.rocket, 12.5, 0.05, device=device, lib=emu_lib)
+        h = owner._h                                          # (owner stays alive: its finaliser destroys the handle)
+        for name in sorted(_lib.SIGNATURES):
+            fn = getattr(cd, name)
+            at = fn.argtypes or []
+            if not at or at[0] is not C.c_void_p or name in ("od_destroy", "od_set_stream", "od_create"):
+                continue
+            args = _zero_args(fn, h)
+            for i, t in enumerate(at):                      # a batch of 4 problems / knots, null buffers
+                if i > 0 and t is C.c_long:
+                    args[i] = 4
+            r = fn(*args)
+            assert isinstance(r, int) and r <= 0 or name in queries, (model, name, r)
+
+
+def test_null_arguments_are_error_codes_not_crashes(emu_lib):
+    """every entry point of the header called with a null handle and null / zero arguments, then with a live handle
+    and null data pointers: an error code (or a harmless query result), never a crash (host build of the same sources)"""
+    _null_fuzz(emu_lib, "cpu")
+
+
+@pytest.mark.gpu
+def test_null_arguments_are_error_codes_not_crashes_on_the_gpu(gpu_lib):
+    _null_fuzz(gpu_lib, "cuda:0")
