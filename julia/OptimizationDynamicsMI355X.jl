@@ -27,6 +27,14 @@ const MODEL_IDS = Dict(:acrobot_impact => 0, :acrobot_nominal => 1, :cartpole_fr
                        :cartpole_frictionless => 3, :planarpush => 4, :rocket => 5,
                        :rocket_projection => 6, :hopper => 7)
 
+# built-in ids, or -- for a model added with `python -m optimization_dynamics_amd.codegen --add` -- the library's registry
+function model_id(sym::Symbol)
+    haskey(MODEL_IDS, sym) && return MODEL_IDS[sym]
+    id = ccall((:od_model_id, LIB), Cint, (Cstring,), string(sym))
+    id < 0 && error("unknown model $sym; built in: $(keys(MODEL_IDS))")
+    return Int(id)
+end
+
 struct ODOptions                      # od_options (include/od_mi355x.h)
     r_tol::Cdouble; kappa_eval_tol::Cdouble; kappa_grad_tol::Cdouble
     max_iter::Cint; max_ls::Cint
@@ -69,7 +77,7 @@ function ImplicitDynamics(model, h, r_func=nothing, rz_func=nothing, rθ_func=no
         no_impact=false, no_friction=false,
         n=nothing, m=nothing, d=0, nc=nothing, nb=nothing, info=nothing)
     sym = model_symbol(model)
-    id = MODEL_IDS[sym]
+    id = model_id(sym)
     dims = [Ref{Cint}(0) for _ in 1:5]
     check(ccall((:od_model_dims, LIB), Cint, (Cint, Ref{Cint}, Ref{Cint}, Ref{Cint}, Ref{Cint}, Ref{Cint}), id, dims...))
     nq, nu = Int(dims[1][]), Int(dims[2][])
@@ -273,7 +281,7 @@ end
 "1-based z indices of (:q | :γ | :b) for a model"
 function model_indices(model::Symbol, which::Symbol)
     buf = zeros(Cint, 16)
-    n = ccall((:od_model_indices, LIB), Cint, (Cint, Cint, Ptr{Cint}, Cint), MODEL_IDS[model], Dict(:q => 0, :γ => 1, :b => 2)[which], buf, 16)
+    n = ccall((:od_model_indices, LIB), Cint, (Cint, Cint, Ptr{Cint}, Cint), model_id(model), Dict(:q => 0, :γ => 1, :b => 2)[which], buf, 16)
     return Int.(buf[1:n]) .+ 1
 end
 
