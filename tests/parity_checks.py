@@ -280,8 +280,7 @@ def check_rocket(oracle, lib, device, B, dtype=torch.float64):
                 eu = np.abs(UP[:, b].double().cpu().numpy() - up).max() / max(1, np.abs(up).max())
                 if (st[b] & 0x33) != 0x33:
                     # a projection that runs out of iterations is a reported status, not an error (the reference warns
-                    # and copies the result out, src/models/rocket/dynamics.jl:178-186): ~0.02 % of solves in fp64,
-                    # ~0.5 % in fp32 on these inputs
+                    # and copies the result out, src/models/rocket/dynamics.jl:178-186): ~0.02 % of solves on these inputs
                     nfail += 1
                     continue
                 # The projection runs with eps_min = 0 (tau = 1): its equality residual sits at rounding
