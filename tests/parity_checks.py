@@ -637,3 +637,78 @@ def check_rollout_finite_undercut(oracle, lib, device, B=6, T=8):
     ok = (st[0].cpu().numpy() & 3) == 3
     assert np.abs(X[:, 1].cpu().numpy() - Do)[:, ok].max() < STATE_TOL
     assert_grad_close(np.concatenate([A[:, :, 0].cpu().numpy(), Bm[:, :, 0].cpu().numpy()], 1), np.concatenate([DXo, DUo], 1), ok, "finite undercut rollout")
+
+
+def check_rollout_instantiation(oracle, lib, device, B, T, B_ref, n_oracle=256, t_chain=(0, 7), seed=23):
+    """One shipped instantiation / launch mapping of the cooperative rollout kernel, selected by the batch size
+    (csrc/od_model_tu.inc: rows per wavefront 1 / 2 / 4 at B <= 1024 / 2048 / more; the two-wavefronts-per-SIMD build
+    `k_rollout_state_coop<., 2>` beyond 4096), held to
+      * rollout == chained od_step_grad on the device's own states, bitwise (state, status, iteration counts);
+      * the oracle's rollout on the first `n_oracle` trajectories, 1e-6 relative on the first knots, median at the end;
+      * the SAME trajectories rolled out in batches of B_ref (another mapping / the one-wavefront-per-SIMD build):
+        identical iteration counts and status on every knot, identical states."""
+    x1, U = W.hopper_rollout_inputs(B, T, seed=seed, u_sigma=0.7)
+    im = make_im("hopper", lib, device)
+    x1d, Ud = torch.tensor(x1, device=device), torch.tensor(U, device=device)
+    assert lib.cdll.od_uses_cooperative(im._h, B) == 1
+    X, G, st, it, _ = im.rollout_compact(x1d, Ud)
+    X, G, st, it = X.clone(), G.clone(), st.clone(), it.clone()
+    assert torch.isfinite(X).all()
+    conv = ((st & 3) == 3)
+    assert conv.double().mean().item() > 0.999
+    for t in t_chain:
+        t = min(t, T - 1)
+        Q3, Gs, s1, i1 = im.step_grad_compact(X[:, t].contiguous(), Ud[:, t].contiguous())
+        assert torch.equal(Q3, X[4:, t + 1]) and torch.equal(s1, st[t]) and torch.equal(i1, it[:, t]), t
+        okk = ((s1 & 3) == 3).cpu().numpy()
+        assert_grad_close(G[:, :, t].cpu().numpy(), Gs.cpu().numpy(), okk, "rollout vs chained step, knot %d" % t)
+    # the other mapping, batch by batch
+    for b0 in range(0, B, B_ref):
+        b1 = min(B, b0 + B_ref)
+        Xr, Gr, str_, itr, _ = im.rollout_compact(x1d[:, b0:b1].contiguous(), Ud[:, :, b0:b1].contiguous())
+        assert torch.equal(itr, it[:, :, b0:b1]) and torch.equal(str_, st[:, b0:b1]), (b0, "iteration counts / status")
+        assert torch.equal(Xr, X[:, :, b0:b1]), (b0, (Xr - X[:, :, b0:b1]).abs().max().item())
+        assert torch.equal(Gr, G[:, :, :, b0:b1])
+    # the oracle on a subset
+    n = min(n_oracle, B)
+    Xo, Ao, Bo, bad = oracle.rollout(make_sim(oracle, "hopper"), np.ascontiguousarray(x1[:, :n]), np.ascontiguousarray(U[:, :, :n]))
+    Xn = X[:, :, :n].cpu().numpy()
+    ok = conv[:, :n].cpu().numpy().all(0)
+    assert ok.mean() > 0.9
+    err = np.abs(Xn - Xo)[:, :, ok].max(0)
+    scale = np.maximum(1e-2, np.abs(Xo)[:, :, ok].max(0))
+    assert (err / scale)[: min(T, 10) + 1].max() < STATE_TOL, (err / scale)[: min(T, 10) + 1].max()
+    assert np.median((err / scale)[-1]) < 1e-6
+    Gn = G[:, :, 0, :n].cpu().numpy()
+    Go = np.concatenate([Ao[4:, :, 0], Bo[4:, :, 0]], 1)
+    assert_grad_close(Gn, Go, ok, "knot 0 vs oracle")
+    return im
+
+
+def check_plumbing_config_callbacks(oracle, lib, device):
+    """BASELINE config 1 through the reference-signature callbacks: cartpole with joint friction, x1 = 0, T = 51 (50 steps),
+    u_1 = -1.5, the rest 0 (examples/cartpole.jl:15-21,41-46,78) -- f for the rollout, then fx and fu at every knot, one
+    host-vector call each (od_f_host / od_fx_host / od_fu_host), like iLQR.rollout + the derivative sweep of the reference"""
+    im = make_im("cartpole_friction", lib, device)
+    T = 50
+    U = np.zeros((1, T, 1)); U[0, 0, 0] = -1.5
+    x = np.zeros(4)
+    Xs = [x.copy()]
+    As, Bs = [], []
+    for t in range(T):
+        d = np.zeros(4); dx = np.zeros((4, 4)); du = np.zeros((4, 1))
+        dyn.fx(dx, im, x, U[:, t, 0]); dyn.fu(du, im, x, U[:, t, 0]); dyn.f(d, im, x, U[:, t, 0])
+        As.append(dx); Bs.append(du)
+        x = d.copy()
+        Xs.append(x.copy())
+    X = np.stack(Xs, 1)[:, :, None]
+    A = np.stack(As, 2)[:, :, :, None]
+    Bm = np.stack(Bs, 2)[:, :, :, None]
+    Xo, Ao, Bo, bad = oracle.rollout(make_sim(oracle, "cartpole_friction"), np.zeros((4, 1)), U)
+    assert bad == 0
+    assert np.abs(X - Xo).max() < 1e-9, np.abs(X - Xo).max()
+    assert W.grad_rel_err(A.reshape(16, T), Ao.reshape(16, T)).max() < 1e-6
+    assert W.grad_rel_err(Bm.reshape(4, T), Bo.reshape(4, T)).max() < 1e-6
+    # and the same sequence as one device call (od_rollout, B = 1): identical states
+    Xd = im.rollout(torch.zeros(4, 1, dtype=torch.float64), torch.tensor(U))[0].cpu().numpy()
+    assert np.array_equal(Xd, X)
