@@ -7,7 +7,13 @@ One "step" = one od_rollout_compact call (two launches: the time recursion, then
 honouring kappa_eval for the state and kappa_grad for the gradient (the reference's f + fx + fu,
 src/dynamics.jl:81-128; fx / fu are these blocks plus constants).  Inputs are resident in HBM
 before the timed region.  Multi-GPU: one process per GPU, trajectories sharded, no data-path
-collective (weak scaling: 4096 rollouts per GPU) -- every trajectory's Riccati pass is rank-local.
+collective -- every trajectory's Riccati pass is rank-local.  The workload is ONE seeded set of trajectories in blocks
+of `--batch` (block k drawn with seed k; block 0 is the single-GPU workload):
+  --scaling weak   (default) rank r rolls out block r: `--batch` rollouts per GPU, N x the work on N GPUs;
+  --scaling strong the metric as BASELINE.json words it -- a FIXED total batch (`--batch`, block 0) sharded over the
+                   ranks (shard_range), value = total units / max-over-ranks time.
+A weak run on N > 1 ranks times the strong mode as well (same K steps, after the headline region) and reports it under
+"strong_scaling", so one driver invocation per N yields both curves.
 `--gather` adds the one exchange the path can have, the all-gather of the linearisation for an outer
 loop that runs elsewhere, in compact form (x+ and dq3/d(q1,q2,u): 2.4x fewer bytes than x+, A, B).
 
@@ -76,6 +82,16 @@ def measured_traffic(batch, horizon, gather):
 def algorithmic_bytes_per_unit():
     nq, nu = HOPPER["nq"], HOPPER["nu"]
     return 8 * ((2 * nq + nu) + nq + nq * (2 * nq + nu))     # 432 B
+
+
+def workload_slice(lo, hi, block, horizon):
+    """trajectories [lo, hi) of the global workload: blocks of `block` trajectories, block k = make_inputs(block, T, seed=k)"""
+    xs, us = [], []
+    for k in range(lo // block, (hi - 1) // block + 1):
+        x1, U = make_inputs(block, horizon, seed=k)
+        a, b = max(lo, k * block) - k * block, min(hi, (k + 1) * block) - k * block
+        xs.append(x1[:, a:b]); us.append(U[:, :, a:b])
+    return np.ascontiguousarray(np.concatenate(xs, 1)), np.ascontiguousarray(np.concatenate(us, 2))
 
 
 def make_inputs(batch, horizon, seed, h=0.05):
@@ -163,7 +179,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=4096, help="rollouts per GPU")
+    ap.add_argument("--batch", type=int, default=4096, help="rollouts per GPU (weak) / in total (strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --batch rollouts per GPU; strong: --batch rollouts in total, sharded over the GPUs (BASELINE.json's wording)")
+    ap.add_argument("--test-dump", default=None, help="TEST HARNESS ONLY: rank 0 writes the gathered (X, G) of the last step to this .npz")
     ap.add_argument("--horizon", type=int, default=100)
     ap.add_argument("--gather", action="store_true", help="all-gather the compact linearisation (x+, dq3) after every step (RCCL)")
     ap.add_argument("--dense", action="store_true", help="write the dense fx / fu matrices (od_rollout) instead of the compact dq3 (od_rollout_compact)")
@@ -214,57 +233,82 @@ def main():
         im.set_launch_config(args.ppw, args.wpb)
     if args.coop:
         im.set_cooperative(args.coop)
-    B, T = args.batch, args.horizon
-    x1, U = make_inputs(B, T, seed=rank)
-    x1d = torch.tensor(x1, device=dev)
-    Ud = torch.tensor(U, device=dev)
+    T = args.horizon
+    from optimization_dynamics_amd.parallel import shard_range
     stream = None if emu else torch.cuda.current_stream(dev)
 
-    out = None
-    gather_bufs = None
+    def inputs_for(mode):
+        """(lo, hi) of this rank in the global workload"""
+        if mode == "weak":
+            return rank * args.batch, (rank + 1) * args.batch
+        return shard_range(args.batch, world, rank)
 
-    def step():
-        nonlocal out, gather_bufs
-        # the unit's outputs exactly: x+ = [q2; q3] and dq3/d(q1, q2, u) (nq x (2nq+nu)) per knot -- od_rollout's dense
-        # A / B are the same numbers padded with the constant [0 I] and zero rows of fx / fu (--dense times those)
-        if args.dense:
-            X, A, Bm, st, it, out = im.rollout(x1d, Ud, out=out)
+    def timed_region(mode, dump=None):
+        """W untimed + K timed steps of this rank's share under `mode`; -> (max-over-ranks seconds, mean event ms, status, iterations, B_local)"""
+        lo, hi = inputs_for(mode)
+        x1, U = workload_slice(lo, hi, args.batch, T)
+        x1d, Ud = torch.tensor(x1, device=dev), torch.tensor(U, device=dev)
+        out = None
+        gather_bufs = None
+
+        def step():
+            nonlocal out, gather_bufs
+            # the unit's outputs exactly: x+ = [q2; q3] and dq3/d(q1, q2, u) (nq x (2nq+nu)) per knot -- od_rollout's dense
+            # A / B are the same numbers padded with the constant [0 I] and zero rows of fx / fu (--dense times those)
+            if args.dense:
+                X, A, Bm, st, it, out = im.rollout(x1d, Ud, out=out)
+                return st, it
+            X, G, st, it, out = im.rollout_compact(x1d, Ud, out=out)
+            if args.gather and world > 1:
+                if gather_bufs is None:
+                    gather_bufs = [torch.empty(world * t.numel(), dtype=t.dtype, device=dev) for t in (out["X"], out["G"])]
+                for buf, t in zip(gather_bufs, (out["X"], out["G"])):
+                    dist.all_gather_into_tensor(buf, t.reshape(-1))
             return st, it
-        X, G, st, it, out = im.rollout_compact(x1d, Ud, out=out)
-        if args.gather and world > 1:
-            if gather_bufs is None:
-                gather_bufs = [torch.empty(world * t.numel(), dtype=t.dtype, device=dev) for t in (out["X"], out["G"])]
-            for buf, t in zip(gather_bufs, (out["X"], out["G"])):
-                dist.all_gather_into_tensor(buf, t.reshape(-1))
-        return st, it
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    if world > 1:
-        dist.barrier()
-    sync()
-    ev = None if emu else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        if ev:
-            ev[k][0].record(stream)      # the rollout kernels are launched on this (torch current) stream
-        st, it = step()
-        if ev:
-            ev[k][1].record(stream)
-    sync()
-    if world > 1:
-        dist.barrier()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        for _ in range(args.warmup):
+            step()
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        ev = None if emu else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            if ev:
+                ev[k][0].record(stream)      # the rollout kernels are launched on this (torch current) stream
+            st, it = step()
+            if ev:
+                ev[k][1].record(stream)
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else elapsed / args.steps * 1e3
+        if dump and rank == 0 and gather_bufs is not None:
+            Bl = hi - lo
+            Xg = gather_bufs[0].view(world, 8, T + 1, Bl).movedim(0, -2).reshape(8, T + 1, world * Bl)
+            Gg = gather_bufs[1].view(world, 10, 4, T, Bl).movedim(0, -2).reshape(10, 4, T, world * Bl).transpose(0, 1)
+            np.savez(dump, X=Xg.cpu().numpy(), G=Gg.cpu().numpy())
+        return elapsed, kernel_ms, st, it, hi - lo
 
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else elapsed / args.steps * 1e3
+    if args.gather and args.scaling == "strong" and args.batch % world:
+        raise SystemExit("bench.py: --gather with --scaling strong needs --batch divisible by the number of ranks (equal shards)")
+    elapsed, kernel_ms, st, it, B = timed_region(args.scaling, dump=args.test_dump)
+    strong = None
+    if world > 1 and args.scaling == "weak" and not (args.gather and args.batch % world):
+        e2, k2, st2, it2, B2 = timed_region("strong")
+        strong = dict(scaling="strong", total_batch=args.batch, rollouts_per_gpu=B2, value=args.batch * T * args.steps / e2,
+                      unit="steps+grads/s", ms_per_step=e2 / args.steps * 1e3, kernel_ms_rank0=k2)
+
     units_per_rank = B * T
-    value = world * units_per_rank * args.steps / elapsed
+    total_units = (world * args.batch if args.scaling == "weak" else args.batch) * T
+    value = total_units * args.steps / elapsed
     stc = torch.bincount(st.flatten(), minlength=8).tolist()
     it_eval = float(it[0].double().mean().item())
     it_max = int(it.max().item())
@@ -298,10 +342,13 @@ def main():
         line = {
             "metric": "contact-implicit steps+grads/sec, hopper T=100 batch=4096",
             "value": value, "unit": "steps+grads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "ranks_seen": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else "none (single process)"),
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "hopper (RoboDojo path-following contact), T=%d, batch=%d rollouts per GPU, "
-                                   "h=0.05, kappa_eval=1e-4, kappa_grad=1e-3, r_tol=1e-8; od_rollout_compact = f+fx+fu per knot (q3, dq3/d(q1,q2,u))" % (T, B),
+            "config": {"workload": "hopper (RoboDojo path-following contact), T=%d, batch=%d rollouts %s, "
+                                   "h=0.05, kappa_eval=1e-4, kappa_grad=1e-3, r_tol=1e-8; od_rollout_compact = f+fx+fu per knot (q3, dq3/d(q1,q2,u))"
+                                   % (T, args.batch, "per GPU" if args.scaling == "weak" else "in total, sharded over the GPUs"),
+                       "total_batch": world * args.batch if args.scaling == "weak" else args.batch,
                        "units_per_step_per_gpu": units_per_rank, "parallelism": "rollouts sharded x%d, no collective%s" % (world, " + all-gather(x+, dq3) compact" if args.gather else "")},
             # the governing roof is the fp64 VECTOR-ALU rate (78.6 TFLOP/s, equal to the fp64 matrix peak on MI355X): the
             # path is arithmetic on 4..20-wide systems with no GEMM-shaped work, nothing here runs on MFMA
@@ -314,6 +361,8 @@ def main():
                          "hbm_algorithmic_GBps": ach_gbs, "hbm_frac": ach_gbs / HBM_PEAK_GBS},
             "solver_status_counts": {"converged(7)": stc[7], "other": int(sum(stc) - stc[7])},
         }
+        if strong is not None:
+            line["strong_scaling"] = strong
         if aux is not None:
             Fk, _, _ = algorithmic_flops_per_unit(aux["mean_iterations"], stats)
             aux["algorithmic_tflops"] = Fk * aux["units_per_s"] / 1e12

@@ -432,6 +432,8 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
     o.write("  // pivoting beyond the cone role swaps%s); gradient solves always use factor<true>\n" % (", pivoted %dx%d configuration tail" % (els.m, els.m) if state_tail_piv else ""))
     o.write("  static constexpr bool STATIC_TAIL = %s;\n" % ("true" if has_state else "false"))
     o.write("  static constexpr int MTAIL_S = %d, TAIL_BASE_S = %d;\n" % (els.m, els.tail_base))
+    o.write("  // factor slots the interior-point iterations touch (a kernel that never takes a gradient stores no more)\n")
+    o.write("  static constexpr int NFACT_S = %d;\n" % (els.slots if has_state else el.slots))
     o.write(arr("ORT1", m.ort[0]) + arr("ORT2", m.ort[1]) + arr("ORTR", m.ortr))
     o.write(arr("SOCOFF", soc_off) + arr("SOC1", soc_flat_p) + arr("SOC2", soc_flat_d) + arr("SOCR", socr_flat))
     o.write(arr("EQUR", m.equr) + arr("BIL", m.bil) + arr("ZQ", m.idx_zq))

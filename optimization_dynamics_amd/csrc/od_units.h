@@ -40,8 +40,8 @@ template <class T> struct View {
 // ---- where the KKT factors of one problem live -------------------------------------------------------------
 // RegFact: the generated Fact struct (registers; what does not fit spills to scratch).  LdsFact: LDS, 16 lane slots
 // per 64-thread workgroup, for models whose factors do not fit the register file anyway (planar push: 325
-// doubles per lane = the whole of its 2.5 KB scratch frame).  LDS is ~10x closer than scratch, but 41.6 KB per
-// wavefront allow only 3 wavefronts per CU, so the launcher uses it when the batch fits one such round
+// doubles per lane = the whole of its 2.5 KB scratch frame).  LDS is ~10x closer than scratch, but 29 KB per
+// wavefront allow only 5 wavefronts per CU, so the launcher uses it when the batch fits one round of the 1024 SIMDs
 // (od_model_tu.inc).  Accesses go through an opaque offset so that the compiler cannot keep the values in
 // registers (and spill those) after all.
 template <class M, class T> struct RegFactStore {
@@ -64,7 +64,11 @@ template <class M, class T> struct LdsFactStore {
     bool sw[M::NSWAP > 0 ? M::NSWAP : 1];
   };
   __device__ __forceinline__ static Fact make() {
-    __shared__ T lds_fact[(M::NFACT > 0 ? M::NFACT : 1) * SLOTS];
+    // the kernels that use this store run the interior-point iterations only (pass 1 defers its gradient, the bundle
+    // takes none): the state program's slots, not the larger pivoted program's -- planar push 229 instead of 325 doubles
+    // per lane = 29 KB instead of 42 KB per wavefront, five wavefronts per CU instead of three: the 804 wavefronts of
+    // BASELINE config 3 are then resident at once (768 were, the last 36 waited for a second round)
+    __shared__ T lds_fact[(M::NFACT_S > 0 ? M::NFACT_S : 1) * SLOTS];
     Fact f;
     f.v.base = lds_fact + (threadIdx.x & (SLOTS - 1));
     return f;
@@ -306,7 +310,7 @@ template <class M, class T> OD_HD void unit_grad_knot(const StepArgs<T>& a, long
 }
 
 template <class T> struct NoGradSink {
-  static constexpr bool DEFER_GRAD = false;
+  static constexpr bool DEFER_GRAD = true;     // (never asked for a gradient: no factor<true> / solve<true> code in the kernel)
   static constexpr bool FULL_STATE = false;
   OD_HD void grad(int, int, T) {}
   OD_HD void defer(const T*, T) {}

@@ -90,3 +90,58 @@ def test_bench_gpus_flag_spawns_ranks(emu_lib):
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
     assert rec["config"]["units_per_step_per_gpu"] == 16 * 6
     assert rec["value"] > 0 and "all-gather" in rec["config"]["parallelism"]
+
+
+def _run_bench(emu_lib, extra, timeout=600):
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "16", "--horizon", "6",
+           "--no-cpu-baseline", "--test-emu-lib", emu_lib.path] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_strong_scaling_shards_the_same_workload(emu_lib, tmp_path):
+    """`bench.py --gpus 2 --scaling strong`: the FIXED batch of the single-GPU run (block 0 of the seeded workload) is
+    sharded over the ranks; gathered result == the unsharded rollout, bit for bit; value counts the batch once"""
+    dump = str(tmp_path / "strong.npz")
+    rec = _run_bench(emu_lib, ["--gpus", "2", "--scaling", "strong", "--gather", "--test-dump", dump])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["scaling"] == "strong" and rec["backend"] == "gloo"
+    assert rec["config"]["total_batch"] == 16 and rec["config"]["units_per_step_per_gpu"] == 8 * 6
+    assert abs(rec["value"] - 16 * 6 * rec["steps"] / (rec["ms_per_step"] * 1e-3 * rec["steps"])) < 1e-6 * rec["value"]
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench
+    import parity_checks as P
+    x1, U = bench.workload_slice(0, 16, 16, 6)
+    x1b, Ub = bench.make_inputs(16, 6, seed=0)
+    assert np.array_equal(x1, x1b) and np.array_equal(U, Ub)          # block 0 IS the single-GPU workload
+    im = P.make_im("hopper", emu_lib, "cpu")
+    X, G, st, it, _ = im.rollout_compact(torch.tensor(x1), torch.tensor(U))
+    g = np.load(dump)
+    assert np.array_equal(g["X"], X.numpy()) and np.array_equal(g["G"], G.numpy())
+
+
+def test_bench_weak_run_reports_strong_mode_too(emu_lib):
+    """a weak run on N > 1 ranks (what the driver launches) times the sharded-fixed-batch mode as well"""
+    rec = _run_bench(emu_lib, ["--gpus", "2"])
+    assert rec["scaling"] == "weak" and rec["config"]["total_batch"] == 32
+    s = rec["strong_scaling"]
+    assert s["scaling"] == "strong" and s["total_batch"] == 16 and s["rollouts_per_gpu"] == 8 and s["value"] > 0
+    rec1 = _run_bench(emu_lib, [])
+    assert rec1["n_gpus"] == 1 and "strong_scaling" not in rec1 and rec1["config"]["total_batch"] == 16
+
+
+def test_workload_slices_are_consistent():
+    sys.path.insert(0, ROOT)
+    import bench
+    a, ua = bench.workload_slice(0, 48, 16, 4)
+    for lo, hi in ((0, 16), (16, 32), (5, 37), (40, 48)):
+        b, ub = bench.workload_slice(lo, hi, 16, 4)
+        assert np.array_equal(b, a[:, lo:hi]) and np.array_equal(ub, ua[:, :, lo:hi])
+    x1, U = bench.make_inputs(16, 4, seed=2)
+    assert np.array_equal(a[:, 32:48], x1)
