@@ -53,9 +53,12 @@ class _DevicePrinter(C99CodePrinter):
     def _print_Pi(self, expr):
         return "T(3.14159265358979323846)"
 
+    def _print_od_rootinv(self, expr):
+        return "od_rootinv<%d>(%s)" % (int(expr.args[1]), self._print(expr.args[0]))
+
     def _print_Pow(self, expr):
         b, e = expr.base, expr.exp
-        if e.is_Integer and 2 <= int(e) <= 12:
+        if e.is_Integer and 2 <= int(e) <= 64:
             return "od_powi<%d>(%s)" % (int(e), self._print(b))
         if e.is_Integer and -12 <= int(e) <= -1:
             if int(e) == -1:
@@ -75,6 +78,49 @@ class _DevicePrinter(C99CodePrinter):
 
     def _print_Abs(self, expr):
         return "od_abs(%s)" % self._print(expr.args[0])
+
+
+class od_rootinv(sp.Function):
+    """od_rootinv(b, Q) = b**(-1/Q) for b > 0 (csrc/od_math.h: single-precision seed + division-free Newton steps)"""
+    nargs = 2
+    is_real = True
+
+
+def rewrite_roots(exprs):
+    """Fractional powers b**(p/q) (q > 2, or q = 2 with |p| > 1) of one base through ONE root u = b**(-1/Q), Q the least
+    common denominator over the base's exponents:  b**(P/Q) = u**(-P) for P < 0,  b**c * u**(c Q - P) for P > 0
+    (c = ceil(P/Q)).  The signed distance of the planar push, (x**10 + y**10)**(1/10), and its first and second
+    derivatives need exponents 1/10, -9/10, -9/5, -19/10, -14/5 of the same sum: one root instead of five calls of the
+    library's pow per Jacobian evaluation (each a few hundred instructions)."""
+    import math
+    exprs = [sp.sympify(e) for e in exprs]
+
+    def frac(e):
+        return e.is_Pow and e.exp.is_Rational and not e.exp.is_Integer and not (e.exp.q == 2 and abs(e.exp.p) == 1)
+
+    # innermost first: the base of an outer fractional power changes when the roots inside it are rewritten
+    for _ in range(8):
+        Q = {}
+        for e in exprs:
+            for pw in e.atoms(sp.Pow):
+                if frac(pw) and not any(frac(x) for x in pw.base.atoms(sp.Pow)):
+                    Q[pw.base] = math.lcm(Q.get(pw.base, 1), int(pw.exp.q))
+        if not Q:
+            return exprs
+
+        def sub(pw):
+            if pw.base not in Q:
+                return pw
+            b, q = pw.base, Q[pw.base]
+            P = int(pw.exp.p) * (q // int(pw.exp.q))
+            u = od_rootinv(b, sp.Integer(q))
+            if P < 0:
+                return u ** (-P)
+            c = -((-P) // q)
+            return b ** c * u ** (c * q - P)
+
+        exprs = [e.replace(lambda x: frac(x) and x.base in Q, sub) for e in exprs]
+    raise AssertionError("nested fractional powers deeper than expected")
 
 
 def _cse_block(exprs: Sequence[sp.Expr], printer, scalar: str, prefix: str) -> Tuple[List[str], List[str]]:
@@ -485,7 +531,7 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
         else:
             r_loop.append(e)
     npre_rows = len(row_pre)
-    repl, red = sp.cse([e for _, e in row_pre] + r_loop + rzv + rthv, symbols=sp.numbered_symbols("x"))
+    repl, red = sp.cse(rewrite_roots([e for _, e in row_pre] + r_loop + rzv + rthv), symbols=sp.numbered_symbols("x"))
     red_rowpre = red[:npre_rows]
     red = red[npre_rows:]
     red_r, red_rz, red_rth = red[:m.nz], red[m.nz:m.nz + nnz], red[m.nz + nnz:]
@@ -497,7 +543,9 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
         fs = e.free_symbols
         dep_z[sy] = any((f in zs) or dep_z.get(f, False) for f in fs)
         dep_ort[sy] = any((f in ortv) or dep_ort.get(f, False) for f in fs)
-    is_trig = {sy: (dep_z[sy] and isinstance(e, (sp.sin, sp.cos))) for sy, e in repl}
+    # z-dependent transcendental values computed by eval_r at the point it is called on and re-used by eval_rz / eval_rth
+    # at the same point: sines, cosines and roots
+    is_trig = {sy: (dep_z[sy] and isinstance(e, (sp.sin, sp.cos, od_rootinv))) for sy, e in repl}
     for sy in tdef:
         if is_trig[sy]:
             assert not dep_ort[sy], "trig of a clamped (orthant) variable cannot be shared between r and rz"
@@ -521,7 +569,7 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
 
     def _w(e):
         c = int(sp.count_ops(e))
-        c += 20 * len(e.atoms(sp.sin, sp.cos))
+        c += 20 * len(e.atoms(sp.sin, sp.cos, od_rootinv))
         c += 3 * sum(1 for p_ in e.atoms(sp.Pow) if p_.exp.is_negative)
         return c
 
@@ -597,7 +645,7 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
             # solver computes two angles side by side in the two halves of a lane row (od_coop.h::TrigHalves)
             targs = []
             for sy, e in repl:
-                if sy in need and is_trig[sy] and sy not in stored:
+                if sy in need and is_trig[sy] and sy not in stored and isinstance(e, (sp.sin, sp.cos)):
                     a_ = e.args[0]
                     if a_ not in targs:
                         targs.append(a_)

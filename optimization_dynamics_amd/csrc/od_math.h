@@ -131,6 +131,38 @@ OD_HD double od_rsqrt(double x) { return 1.0 / sqrt(x); }
 OD_HD float od_rsqrt(float x) { return 1.0f / sqrtf(x); }
 #endif
 
+// x^(-1/Q) for x > 0, Q >= 2 known at code-generation time (codegen/emit.py::rewrite_roots: the fractional powers of one base
+// become integer powers of this root).  Device: seed 2^(-log2(x)/Q) from the single-precision transcendental units
+// (v_log_f32 / v_exp_f32, ~2e-7 relative for the operands met here), then division-free Newton steps on
+// f(u) = u^-Q - x:  u <- u + u (1 - x u^Q) / Q,  error e -> (Q + 1)/2 e^2: two steps reach the rounding floor (the
+// residual 1 - x u^Q is one FMA).  Operands outside the range of the single-precision seed take the library's pow.
+template <int N, class T> OD_HD T od_powi(T x);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OD_EXACT_RCP)
+template <int Q> __device__ __forceinline__ double od_rootinv(double x) {
+  if constexpr (Q == 2) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double nhx = -0.5 * x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) y = __builtin_fma(__builtin_fma(nhx * y, y, 0.5), y, y);
+    return y;
+  } else {
+    const float xf = (float)x;
+    if (!(xf > 1e-30f && xf < 1e30f)) return pow(x, -1.0 / Q);
+    double u = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xf) * (-1.0f / Q));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const double e = __builtin_fma(-x, od_powi<Q>(u), 1.0);
+      u = __builtin_fma(u * (1.0 / Q), e, u);
+    }
+    return u;
+  }
+}
+template <int Q> __device__ __forceinline__ float od_rootinv(float x) { return powf(x, -1.0f / Q); }
+#else
+template <int Q> OD_HD double od_rootinv(double x) { return Q == 2 ? 1.0 / sqrt(x) : pow(x, -1.0 / Q); }
+template <int Q> OD_HD float od_rootinv(float x) { return Q == 2 ? 1.0f / sqrtf(x) : powf(x, -1.0f / Q); }
+#endif
+
 // true if the predicate holds in any active lane of the wavefront (a scalar branch on the device)
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ bool od_any_lane(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0; }
