@@ -21,6 +21,7 @@ import time
 
 from . import models as M
 from .coop import emit_coop
+from .coop3 import emit_coop3
 from .emit import Derived, emit_device, emit_oracle, emit_oracle_table, stats
 
 DEFAULT_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -76,6 +77,14 @@ def main(argv):
                 f.write(coop)
         elif os.path.exists(coop_path):
             os.remove(coop_path)
+        # the 8-lanes-per-problem form (cones of dimension 2 and 3, csrc/od_coop3.h): for the models the 16-lane form rejects
+        coop3 = emit_coop3(m, d) if (coop is None and m.kind == "mech" and (m.soc or m.ort[0])) else None
+        coop3_path = os.path.join(dev_dir, "coop3_" + name + ".h")
+        if coop3 is not None:
+            with open(coop3_path, "w") as f:
+                f.write(coop3)
+        elif os.path.exists(coop3_path):
+            os.remove(coop3_path)
         all_stats[name] = stats(m, d)
         print("%-24s %6.1fs  %s" % (name, time.time() - t0, all_stats[name]), flush=True)
     json.dump(all_stats, open(stats_path, "w"), indent=1, sort_keys=True)

@@ -478,6 +478,8 @@ def emit_device(m: ModelSpec, d: Derived) -> str:
     o.write("  // pivoting beyond the cone role swaps%s); gradient solves always use factor<true>\n" % (", pivoted %dx%d configuration tail" % (els.m, els.m) if state_tail_piv else ""))
     o.write("  static constexpr bool STATIC_TAIL = %s;\n" % ("true" if has_state else "false"))
     o.write("  static constexpr int MTAIL_S = %d, TAIL_BASE_S = %d;\n" % (els.m, els.tail_base))
+    o.write("  // whether the configuration block of the interior-point iterations is factored with runtime partial pivoting\n")
+    o.write("  static constexpr bool STATE_TAIL_PIVOT = %s;\n" % ("true" if ((not has_state) or state_tail_piv) else "false"))
     o.write("  // factor slots the interior-point iterations touch (a kernel that never takes a gradient stores no more)\n")
     o.write("  static constexpr int NFACT_S = %d;\n" % (els.slots if has_state else el.slots))
     o.write(arr("ORT1", m.ort[0]) + arr("ORT2", m.ort[1]) + arr("ORTR", m.ortr))

@@ -147,6 +147,62 @@ __global__ __launch_bounds__(OD_BLOCK) void k_ls_solve_fixed(long B, const doubl
   if (status.ok()) status.at(0, b) = (ok && chk == chk) ? 1 : 0;
 }
 
+// the whole fit of one knot in ONE workgroup (compile-time sizes): the N samples are staged in LDS in chunks, thread e owns
+// entry e of [G | R'] (the same N-term sums, in the same order, as k_ls_accumulate), then thread a < NY factors G in
+// registers and solves for row a of M.  One launch instead of two, no round trip of the normal equations through HBM:
+// BASELINE config 3 (50 knots, N = 256): 62 + 18 us -> see profiles/r3_planar_push_coop3.json.
+#if defined(__HIPCC__)
+template <int NZB, int NY>
+__global__ __launch_bounds__(256) void k_ls_fit_fused(long B, int N, const double* eta, View<const double> feta, View<double> dz, View<int> status) {
+  constexpr int NE = NZB * (NZB + NY), CH = 256, LD = CH + 1;
+  __shared__ double s_eta[NZB * LD], s_df[NY * LD], s_acc[NE];
+  const long b = blockIdx.x;
+  const int t = threadIdx.x;
+  const long p0 = b * (N + 1);
+  const int r = t % NZB, c = t / NZB;
+  double fz[NY];
+#pragma unroll
+  for (int a = 0; a < NY; ++a) fz[a] = feta.at(a, p0);
+  double acc = 0.0;
+  for (int i0 = 0; i0 < N; i0 += CH) {
+    const int i = i0 + t;
+    __syncthreads();
+    if (i < N) {
+#pragma unroll
+      for (int k = 0; k < NZB; ++k) s_eta[k * LD + t] = eta[k + (long)NZB * i];
+#pragma unroll
+      for (int a = 0; a < NY; ++a) s_df[a * LD + t] = feta.at(a, p0 + 1 + i) - fz[a];
+    }
+    __syncthreads();
+    if (t < NE) {
+      const int n = (N - i0 < CH) ? N - i0 : CH;
+      const double* u = s_eta + r * LD;
+      const double* v = (c < NZB) ? s_eta + c * LD : s_df + (c - NZB) * LD;
+      for (int k = 0; k < n; ++k) acc += u[k] * v[k];
+    }
+  }
+  if (t < NE) s_acc[t] = acc;
+  __syncthreads();
+  if (t < NY) {
+    double A[NZB * NZB], x[NZB];
+    int piv[NZB];
+#pragma unroll
+    for (int k = 0; k < NZB * NZB; ++k) A[k] = s_acc[k];
+    const bool ok = od_lu_factor<double, NZB>(A, piv);
+#pragma unroll
+    for (int k = 0; k < NZB; ++k) x[k] = s_acc[NZB * NZB + k + NZB * t];       // G symmetric: row t of M solves G x = R(t,:)'
+    od_lu_solve<double, NZB>(A, piv, x);
+    double chk = 0.0;
+#pragma unroll
+    for (int k = 0; k < NZB; ++k) { dz.at(t + NY * k, b) = x[k]; chk += x[k] * 0.0; }
+    // status: 1 = Gram matrix factorised and every row of the fit finite (a sample may carry a failed solve's NaN)
+    const bool fine = ok && chk == chk;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(!fine);
+    if (t == 0 && status.ok()) status.at(0, b) = (m & ((1ull << NY) - 1ull)) ? 0 : 1;
+  }
+}
+#endif
+
 // ---- iLQR backward pass (Riccati recursion), one lane per trajectory; runtime sizes n <= 16, m <= 12 --------
 // Gauss-Newton iLQR with the quadratic cost model supplied per knot (IterativeLQR's backward pass as recalled,
 // SURVEY.md Appendix A; first-order dynamics only):
@@ -377,12 +433,11 @@ int ppw_of(const od_handle_s* h, long n) { return h->ppw > 0 ? h->ppw : od_auto_
 // The cooperative kernels put one problem on 16 lanes (4 per wavefront): they shorten the critical path of a problem
 // and pay off while the batch leaves lanes idle -- up to OD_COOP_AUTO_MAX problems (measured: 8192 rollouts 5.4 ms against 5.7, 16384 10.4 against 6.6);
 // larger batches fill the lanes with whole problems instead.
-constexpr long OD_COOP_AUTO_MAX = 8192;
 LaunchCfg cfg_of(const od_handle_s* h, long n) {
   LaunchCfg c;
   c.ppw = ppw_of(h, n);
   c.wpb = h->wpb > 0 ? h->wpb : 4;
-  c.coop = h->vt->has_coop && (h->coop == 2 || (h->coop == 0 && h->vt->has_coop == 2 && h->ppw == 0 && n <= OD_COOP_AUTO_MAX));
+  c.coop = h->vt->has_coop && (h->coop == 2 || (h->coop == 0 && h->vt->has_coop == 2 && h->ppw == 0 && n <= h->vt->coop_auto_max));
   return c;
 }
 
@@ -871,6 +926,18 @@ size_t od_bundle_workspace_bytes(od_handle h, long B, int N) {
 static int run_ls(od_handle h, long B, int N, int ny, int nzb, const double* eta, View<const double> fv, double* acc,
                   void* M, int* status) {
   const long ne = (long)nzb * (nzb + ny);
+#if defined(__HIPCC__)
+  {
+    View<double> Mf = mkview<double>(M, ny * nzb, B, h->layout);
+    View<int> sf = mkview<int>(status, 1, B, h->layout);
+    bool fused = true;
+    if (nzb == 12 && ny == 5) hipLaunchKernelGGL((k_ls_fit_fused<12, 5>), dim3((unsigned)B), dim3(256), 0, h->stream, B, N, eta, fv, Mf, sf);        // planar push
+    else if (nzb == 10 && ny == 4) hipLaunchKernelGGL((k_ls_fit_fused<10, 4>), dim3((unsigned)B), dim3(256), 0, h->stream, B, N, eta, fv, Mf, sf);   // hopper
+    else if (nzb == 5 && ny == 2) hipLaunchKernelGGL((k_ls_fit_fused<5, 2>), dim3((unsigned)B), dim3(256), 0, h->stream, B, N, eta, fv, Mf, sf);     // acrobot, cartpole
+    else fused = false;
+    if (fused) { OD_HIP(hipGetLastError()); return OD_OK; }
+  }
+#endif
   hipLaunchKernelGGL(k_ls_accumulate, od_grid(B * ne, OD_BLOCK), dim3(OD_BLOCK), 0, h->stream, B, N, ny, nzb, eta, fv, acc);
   OD_HIP(hipGetLastError());
   View<double> Mv = mkview<double>(M, ny * nzb, B, h->layout);
@@ -903,7 +970,7 @@ int od_bundle_grad(od_handle h, long B, int N, const void* x, const void* u, con
   // workspace layout: feta (nq*P doubles) | normal-equation entries (nzb*(nzb+nq)*B doubles) | sample status (P ints)
   double* acc = (double*)ws + (size_t)nq * P;
   a.status.p = (int*)(acc + (size_t)nzb * (nzb + nq) * B);
-  OD_HIP(h->vt->bundle(a, P, ppw_of(h, P), h->stream));
+  OD_HIP(h->vt->bundle(a, P, cfg_of(h, P), h->stream));
   return run_ls(h, B, N, nq, nzb, (const double*)eta, fv, acc, dz, status);
 }
 

@@ -16,14 +16,15 @@ struct ModelVT {
   double r_tol, kappa_eval, kappa_grad, eps_min, kappa_reg, gamma_reg, undercut;
   int max_iter, max_ls;
   double fric_default[4];
-  int has_coop;                                // cooperative (16 lanes per problem) state kernels: 0 none, 1 on request, 2 automatic for small batches
+  int has_coop;                                // cooperative (16 or 8 lanes per problem) state kernels: 0 none, 1 on request, 2 automatic for small batches
+  long coop_auto_max;                          // ... up to this many problems
   int ngam, nbfr;                              // z indices of the impact / friction impulses
   std::array<int, 12> gam, bfr;
   hipError_t (*step_state)(const StepArgs<double>&, LaunchCfg, hipStream_t);        // pass 1, independent knots
   hipError_t (*rollout_state)(const RolloutArgs<double>&, LaunchCfg, hipStream_t);  // pass 1, rollouts
   hipError_t (*grad_knots)(const StepArgs<double>&, hipStream_t);                   // pass 2 (a.B knots)
   hipError_t (*rollout_policy)(const PolicyArgs<double>&, LaunchCfg, hipStream_t);  // closed-loop rollouts
-  hipError_t (*bundle)(const BundleArgs<double>&, long, int ppw, hipStream_t);
+  hipError_t (*bundle)(const BundleArgs<double>&, long, LaunchCfg, hipStream_t);
   hipError_t (*step_full)(const FullArgs<double>&, int ppw, hipStream_t);           // z and dz, every row
   hipError_t (*raw64)(const RawArgs<double>&, int ppw, hipStream_t);
   hipError_t (*raw32)(const RawArgs<float>&, int ppw, hipStream_t);

@@ -1,0 +1,150 @@
+"""8-lanes-per-problem cooperative solve pass for cones up to dimension 3 (csrc/od_coop3.h; planar push: one contact, four 3-d
+friction cones, one 2-d cone in six lanes).  CPU tier: the 8-lane group is emulated lane by lane (Row8Emu, tests/host_emu) --
+the same block algebra, routing tables and reductions as on the device.  GPU tier: the bank-masked 64-bit DPP instructions."""
+import numpy as np
+import pytest
+import torch
+
+import parity_checks as P
+import workloads as W
+
+NAME = "planar_push"
+
+
+def _pair(lib, device, B, seed=31, **opts):
+    X, U = W.knots(NAME, B, seed=seed)
+    Xd, Ud = torch.tensor(X, device=device), torch.tensor(U, device=device)
+    out = []
+    for mode in (1, 2):
+        im = P.make_im(NAME, lib, device)
+        if opts:
+            im.set_options(**opts)
+        im.set_cooperative(mode)
+        assert lib.cdll.od_uses_cooperative(im._h, B) == (mode == 2)
+        out.append([t.cpu().numpy() for t in im.step_grad(Xd, Ud)] + [im.step(Xd, Ud)[0].cpu().numpy()])
+    return X, U, out[0], out[1]
+
+
+def _vs_lane_per_problem(lib, device, B):
+    X, U, ref, got = _pair(lib, device, B)
+    same = (ref[3] == got[3]) & (ref[4] == got[4]).all(0)
+    assert same.mean() >= 0.999, same.mean()
+    ok = ((ref[3] & 3) == 3) & ((got[3] & 3) == 3)
+    assert ok.mean() > 0.99
+    e = np.abs(ref[0] - got[0]).max(0)[ok & same]
+    assert np.median(e) < 1e-14 and np.quantile(e, 0.99) < 1e-10 and e.max() < 1e-7, (np.median(e), e.max())
+    assert np.array_equal(got[5], got[0])                                   # od_step == od_step_grad state
+    g = W.grad_rel_err(np.concatenate([ref[1], ref[2]], 1), np.concatenate([got[1], got[2]], 1))[ok & same]
+    assert np.median(g) < 1e-11 and (g < P.GRAD_TOL).mean() > 0.99
+
+
+def test_planar_push_has_cooperative_kernels(emu_lib):
+    im = P.make_im(NAME, emu_lib, "cpu")
+    uses = emu_lib.cdll.od_uses_cooperative
+    assert uses(im._h, 12850) == 1 and uses(im._h, 1 << 20) == 0          # automatic for small batches
+    im.set_cooperative(1); assert uses(im._h, 64) == 0
+    im.set_cooperative(0); im.set_launch_config(16, 4); assert uses(im._h, 64) == 0     # an explicit mapping wins
+
+
+def test_coop3_matches_lane_per_problem_emulated(emu_lib):
+    _vs_lane_per_problem(emu_lib, "cpu", 512)
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 9, 17, 2049, 4099])
+def test_coop3_ragged_batches_emulated(emu_lib, B):
+    """2, 4 and 8 problems per wavefront, groups past the end of the batch"""
+    X, U = W.knots(NAME, 4099, seed=83)
+    im = P.make_im(NAME, emu_lib, "cpu")
+    im.set_cooperative(2)
+    full = im.step(torch.tensor(X), torch.tensor(U))
+    part = im.step(torch.tensor(np.ascontiguousarray(X[:, :B])), torch.tensor(np.ascontiguousarray(U[:, :B])))
+    for a, b in zip(full, part):
+        assert torch.equal(a[..., :B], b)
+
+
+def test_coop3_against_oracle_emulated(oracle, emu_lib):
+    im, X, U, out = P.check_step_grad(oracle, emu_lib, "cpu", NAME, 256)
+    assert emu_lib.cdll.od_uses_cooperative(im._h, 256) == 1
+
+
+def test_coop3_bundle_emulated(oracle, emu_lib):
+    P.check_bundle(oracle, emu_lib, "cpu", NAME, 4, 48)
+
+
+def _rollout(oracle, lib, device, B, T):
+    rng = np.random.default_rng(5 + W.SEED_OFFSET)
+    q0 = np.array([0.0, 0.0, 0.0, -0.1 - 1e-8, -0.01])[:, None] + np.r_[np.zeros((4, B)), rng.normal(0, 0.02, (1, B))]
+    x1 = np.vstack([q0, q0])
+    U = np.zeros((2, T, B)); U[0, : T // 2] = rng.uniform(0.3, 0.6, (T // 2, B))      # (harder pushes leave knots at max_iter, in the oracle too); U[1] = rng.normal(0, 0.1, (T, B))
+    im = P.make_im(NAME, lib, device)
+    im.set_cooperative(2)
+    x1d, Ud = torch.tensor(x1, device=device), torch.tensor(U, device=device)
+    X, A, Bm, st, it, _ = im.rollout(x1d, Ud)
+    X, st, it = X.clone(), st.clone(), it.clone()
+    for t in (0, T - 1):
+        D, DX, DU, s1, i1 = im.step_grad(X[:, t].contiguous(), Ud[:, t].contiguous())
+        assert torch.equal(D, X[:, t + 1]) and torch.equal(s1, st[t]) and torch.equal(i1, it[:, t])
+    Xo, Ao, Bo, bad = oracle.rollout(P.make_sim(oracle, NAME), x1, U)
+    ok = ((st.cpu().numpy() & 3) == 3).all(0)
+    assert ok.mean() > 0.9
+    err = np.abs(X.cpu().numpy() - Xo)[:, :, ok].max(0) / np.maximum(1e-2, np.abs(Xo)[:, :, ok].max(0))
+    assert err.max() < P.STATE_TOL, err.max()
+    im.set_cooperative(1)
+    X1, _, _, st1, it1, _ = im.rollout(x1d, Ud)
+    assert (it1 == it).double().mean().item() > 0.995 and (X1 - X).abs().max().item() < 1e-7
+
+
+def test_coop3_rollout_emulated(oracle, emu_lib):
+    _rollout(oracle, emu_lib, "cpu", 6, 10)
+
+
+EDGE_OPTIONS = [dict(max_iter=0), dict(max_iter=2), dict(max_ls=1), dict(kappa_grad_tol=1e-6), dict(r_tol=1e-3), dict(undercut=5.0), dict(gamma_reg=0.0)]
+
+
+def _edge(lib, device, kw):
+    X, U, ref, got = _pair(lib, device, 64, seed=7, **kw)
+    same = (ref[3] == got[3]) & (ref[4] == got[4]).all(0)
+    assert same.mean() >= 0.95, (kw, same.mean())
+    fin = np.isfinite(ref[0]).all(0) & np.isfinite(got[0]).all(0)
+    e = np.abs(ref[0] - got[0]).max(0)[same & fin]
+    assert np.median(e) < 1e-12 and e.max() < 1e-6, (kw, np.median(e), e.max())
+
+
+@pytest.mark.parametrize("kw", EDGE_OPTIONS, ids=lambda d: ",".join("%s=%g" % kv for kv in d.items()))
+def test_coop3_edge_options_emulated(emu_lib, kw):
+    _edge(emu_lib, "cpu", kw)
+
+
+# ---- GPU tier -------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_coop3_matches_lane_per_problem(gpu_lib):
+    _vs_lane_per_problem(gpu_lib, "cuda:0", 8192)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 2, 3, 9, 17, 2049, 4099])
+def test_coop3_ragged_batches(gpu_lib, B):
+    X, U = W.knots(NAME, B, seed=81)
+    im = P.make_im(NAME, gpu_lib, "cuda:0")
+    Xd, Ud = torch.tensor(X, device="cuda:0"), torch.tensor(U, device="cuda:0")
+    im.set_cooperative(2); a = im.step_grad(Xd, Ud)
+    im.set_cooperative(1); b = im.step_grad(Xd, Ud)
+    same = (a[3] == b[3]) & (a[4] == b[4]).all(0)
+    assert same.float().mean().item() >= 0.999 and (a[0] - b[0])[:, same].abs().max().item() < 1e-8
+
+
+@pytest.mark.gpu
+def test_coop3_against_oracle(oracle, gpu_lib):
+    im, X, U, out = P.check_step_grad(oracle, gpu_lib, "cuda:0", NAME, 1024)
+    assert gpu_lib.cdll.od_uses_cooperative(im._h, 1024) == 1
+
+
+@pytest.mark.gpu
+def test_coop3_rollout(oracle, gpu_lib):
+    _rollout(oracle, gpu_lib, "cuda:0", 64, 30)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", EDGE_OPTIONS, ids=lambda d: ",".join("%s=%g" % kv for kv in d.items()))
+def test_coop3_edge_options(gpu_lib, kw):
+    _edge(gpu_lib, "cuda:0", kw)
