@@ -91,9 +91,11 @@ int od_set_stream(od_handle h, void* hip_stream);
  * -- a wavefront is as slow as its slowest lane, so small batches are spread over more wavefronts.
  * waves_per_block: 1 or 4 wavefronts per workgroup (4 = one per SIMD of a CU), 0 = automatic. */
 int od_set_launch_config(od_handle h, int ppw, int waves_per_block);
-/* cooperative solve pass (one problem per 16 lanes, the contacts / cones of a problem spread over them): shortens the
- * critical path of small batches.  mode 0 = automatic (batches that leave lanes idle, models that have the kernels),
- * 1 = never, 2 = always where the model has them.  Results agree with the lane-per-problem kernels to rounding. */
+/* cooperative solve pass (one problem per 16 or per 8 lanes, the contacts / cones of a problem spread over them): shortens
+ * the critical path of a problem.  mode 0 = automatic (per model and batch size), 1 = never (lane-per-problem kernels),
+ * 2 = always where the model has them (the 16-lane form where it has both), 3 = always, the 8-lane form first.
+ * Results agree with the lane-per-problem kernels to rounding; which kernel the automatic mode picks depends on the batch
+ * size, so pin a mode where results must not depend on it at rounding level. */
 int od_set_cooperative(od_handle h, int mode);
 /* diagnostics: the iterate at which the last od_step_grad* / od_rollout* call on this handle differentiated each of its
  * K knots -- z at the first iterate satisfying (r_tol, kappa_grad) and, in row nz, the clamp of the orthant variables

@@ -77,8 +77,10 @@ def main(argv):
                 f.write(coop)
         elif os.path.exists(coop_path):
             os.remove(coop_path)
-        # the 8-lanes-per-problem form (cones of dimension 2 and 3, csrc/od_coop3.h): for the models the 16-lane form rejects
-        coop3 = emit_coop3(m, d) if (coop is None and m.kind == "mech" and (m.soc or m.ort[0])) else None
+        # the 8-lanes-per-problem form (cones of dimension 2 and 3, csrc/od_coop3.h): for the models the 16-lane form rejects,
+        # and beside it for the models with enough contacts / cones to share out (twice the problems per wavefront: larger batches)
+        nroles = len(m.ort[0]) + len(m.soc)
+        coop3 = emit_coop3(m, d) if (m.kind == "mech" and nroles > 0 and (coop is None or nroles >= 4)) else None
         coop3_path = os.path.join(dev_dir, "coop3_" + name + ".h")
         if coop3 is not None:
             with open(coop3_path, "w") as f:

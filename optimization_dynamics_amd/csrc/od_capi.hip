@@ -437,7 +437,17 @@ LaunchCfg cfg_of(const od_handle_s* h, long n) {
   LaunchCfg c;
   c.ppw = ppw_of(h, n);
   c.wpb = h->wpb > 0 ? h->wpb : 4;
-  c.coop = h->vt->has_coop && (h->coop == 2 || (h->coop == 0 && h->vt->has_coop == 2 && h->ppw == 0 && n <= h->vt->coop_auto_max));
+  // cooperative kernels: od_set_cooperative 1 = never, 2 = wherever the model has them (16 lanes per problem first), 3 = the
+  // 8-lane form first; automatic (0, and no explicit lane mapping): 16 lanes up to the model's coop_auto_max problems, 8 lanes
+  // up to coop8_auto_max
+  const ModelVT* vt = h->vt;
+  c.coop = 0;
+  if (h->coop == 2) c.coop = vt->has_coop ? 1 : (vt->has_coop8 ? 2 : 0);
+  else if (h->coop == 3) c.coop = vt->has_coop8 ? 2 : (vt->has_coop ? 1 : 0);
+  else if (h->coop == 0 && h->ppw == 0) {
+    if (vt->has_coop == 2 && n <= vt->coop_auto_max) c.coop = 1;
+    else if (vt->has_coop8 == 2 && n <= vt->coop8_auto_max) c.coop = 2;
+  }
   return c;
 }
 
@@ -772,7 +782,7 @@ int od_set_stream(od_handle h, void* s) {
   return OD_OK;
 }
 int od_set_cooperative(od_handle h, int mode) {
-  if (!h || mode < 0 || mode > 2) return fail(OD_ERR_INVALID, "od_set_cooperative: mode 0 (automatic), 1 (never) or 2 (always)");
+  if (!h || mode < 0 || mode > 3) return fail(OD_ERR_INVALID, "od_set_cooperative: mode 0 (automatic), 1 (never), 2 (always; 16 lanes per problem where the model has both forms) or 3 (always; 8 lanes per problem first)");
   h->coop = mode;
   return OD_OK;
 }

@@ -7,7 +7,7 @@
 
 namespace od {
 
-struct LaunchCfg { int ppw, wpb, coop; };     // problems per wavefront (pow2 <= 64), wavefronts per workgroup (1 | 4), cooperative kernel (od_coop.h)
+struct LaunchCfg { int ppw, wpb, coop; };     // problems per wavefront (pow2 <= 64), wavefronts per workgroup (1 | 4), cooperative kernel: 0 none, 1 = 16 lanes per problem (od_coop.h), 2 = 8 lanes (od_coop3.h)
 
 struct ModelVT {
   int id, kind;
@@ -16,8 +16,10 @@ struct ModelVT {
   double r_tol, kappa_eval, kappa_grad, eps_min, kappa_reg, gamma_reg, undercut;
   int max_iter, max_ls;
   double fric_default[4];
-  int has_coop;                                // cooperative (16 or 8 lanes per problem) state kernels: 0 none, 1 on request, 2 automatic for small batches
+  int has_coop;                                // cooperative state kernels, 16 lanes per problem: 0 none, 1 on request, 2 automatic for small batches
   long coop_auto_max;                          // ... up to this many problems
+  int has_coop8;                               // the same for the 8-lanes-per-problem form (cones up to dimension 3)
+  long coop8_auto_max;
   int ngam, nbfr;                              // z indices of the impact / friction impulses
   std::array<int, 12> gam, bfr;
   hipError_t (*step_state)(const StepArgs<double>&, LaunchCfg, hipStream_t);        // pass 1, independent knots

@@ -639,14 +639,15 @@ def check_rollout_finite_undercut(oracle, lib, device, B=6, T=8):
     assert_grad_close(np.concatenate([A[:, :, 0].cpu().numpy(), Bm[:, :, 0].cpu().numpy()], 1), np.concatenate([DXo, DUo], 1), ok, "finite undercut rollout")
 
 
-def check_rollout_instantiation(oracle, lib, device, B, T, B_ref, n_oracle=256, t_chain=(0, 7), seed=23):
-    """One shipped instantiation / launch mapping of the cooperative rollout kernel, selected by the batch size
-    (csrc/od_model_tu.inc: rows per wavefront 1 / 2 / 4 at B <= 1024 / 2048 / more; the two-wavefronts-per-SIMD build
-    `k_rollout_state_coop<., 2>` beyond 4096), held to
+def check_rollout_instantiation(oracle, lib, device, B, T, B_ref, n_oracle=256, t_chain=(0, 7), seed=23, same_form=True):
+    """One shipped launch mapping of the cooperative rollout kernels, selected by the batch size (csrc/od_model_tu.inc:
+    16 lanes per problem with 1 / 2 / 4 rows per wavefront at B <= 1024 / 2048 / 4096; 8 lanes per problem -- od_coop3.h --
+    with 8 problems per wavefront up to 8192), held to
       * rollout == chained od_step_grad on the device's own states, bitwise (state, status, iteration counts);
       * the oracle's rollout on the first `n_oracle` trajectories, 1e-6 relative on the first knots, median at the end;
-      * the SAME trajectories rolled out in batches of B_ref (another mapping / the one-wavefront-per-SIMD build):
-        identical iteration counts and status on every knot, identical states."""
+      * the SAME trajectories rolled out in batches of B_ref (another mapping): identical iteration counts and status on
+        every knot and identical states if both are mappings of one kernel form (`same_form`); across the two forms (the
+        same arithmetic in another association order) states to rounding and the counts equal on >= 99.5 % of the knots."""
     x1, U = W.hopper_rollout_inputs(B, T, seed=seed, u_sigma=0.7)
     im = make_im("hopper", lib, device)
     x1d, Ud = torch.tensor(x1, device=device), torch.tensor(U, device=device)
@@ -666,9 +667,19 @@ def check_rollout_instantiation(oracle, lib, device, B, T, B_ref, n_oracle=256, 
     for b0 in range(0, B, B_ref):
         b1 = min(B, b0 + B_ref)
         Xr, Gr, str_, itr, _ = im.rollout_compact(x1d[:, b0:b1].contiguous(), Ud[:, :, b0:b1].contiguous())
-        assert torch.equal(itr, it[:, :, b0:b1]) and torch.equal(str_, st[:, b0:b1]), (b0, "iteration counts / status")
-        assert torch.equal(Xr, X[:, :, b0:b1]), (b0, (Xr - X[:, :, b0:b1]).abs().max().item())
-        assert torch.equal(Gr, G[:, :, :, b0:b1])
+        if same_form:
+            assert torch.equal(itr, it[:, :, b0:b1]) and torch.equal(str_, st[:, b0:b1]), (b0, "iteration counts / status")
+            assert torch.equal(Xr, X[:, :, b0:b1]), (b0, (Xr - X[:, :, b0:b1]).abs().max().item())
+            assert torch.equal(Gr, G[:, :, :, b0:b1])
+        else:
+            assert (itr == it[:, :, b0:b1]).double().mean().item() > 0.995
+            both = (((str_ & 3) == 3) & ((st[:, b0:b1] & 3) == 3)).all(0)
+            d = (Xr - X[:, :, b0:b1]).abs()[:, :, both]
+            # (rounding on almost every knot; a solution that is only determined to r_tol = 1e-8 -- knots with 11-13 iterations,
+            # DESIGN.md 3.5 -- moves by up to that; trajectories then diverge at the rate of the dynamics)
+            d0 = d[:, : min(T, 5) + 1].flatten()
+            assert d0.max().item() < 1e-7 and torch.quantile(d0, 0.999).item() < 1e-10, (d0.max().item(), torch.quantile(d0, 0.999).item())
+            assert d.median().item() < 1e-12 and d.max().item() < 1e-5, (d.max().item(), d.median().item())
     # the oracle on a subset
     n = min(n_oracle, B)
     Xo, Ao, Bo, bad = oracle.rollout(make_sim(oracle, "hopper"), np.ascontiguousarray(x1[:, :n]), np.ascontiguousarray(U[:, :, :n]))

@@ -15,13 +15,16 @@ def test_models_with_cooperative_kernels(emu_lib):
     from optimization_dynamics_amd import models
     hop, acro = P.make_im("hopper", emu_lib, "cpu"), P.make_im("acrobot_impact", emu_lib, "cpu")
     uses = emu_lib.cdll.od_uses_cooperative
-    assert uses(hop._h, 4096) == 1 and uses(hop._h, 8192) == 1 and uses(hop._h, 16384) == 0       # automatic: small batches
+    assert uses(hop._h, 4096) == 1 and uses(hop._h, 8192) == 1 and uses(hop._h, 16384) == 0       # automatic: small batches (16 lanes per problem up to 4096, 8 lanes up to 8192)
     assert uses(acro._h, 1024) == 0                                                                  # on request only
     acro.set_cooperative(2); assert uses(acro._h, 1024) == 1
     hop.set_cooperative(1); assert uses(hop._h, 64) == 0
     hop.set_cooperative(0); hop.set_launch_config(16, 4); assert uses(hop._h, 64) == 0               # an explicit mapping wins
     im = P.make_im("planar_push", emu_lib, "cpu")
-    im.set_cooperative(2)                     # no cooperative kernels for this model (3-d cones): silently the usual ones
+    im.set_cooperative(2)                     # 3-d cones: the 8-lane form (od_coop3.h, tests/test_coop3.py)
+    assert uses(im._h, 64) == 1
+    im = P.make_im("acrobot_nominal", emu_lib, "cpu")
+    im.set_cooperative(2)                     # no cones, no cooperative kernels: silently the usual ones
     assert uses(im._h, 64) == 0
     im = P.make_im("cartpole_frictionless", emu_lib, "cpu")
     im.set_cooperative(2)
@@ -29,7 +32,7 @@ def test_models_with_cooperative_kernels(emu_lib):
     a = im.step(torch.tensor(X), torch.tensor(U))[0]
     im.set_cooperative(1)
     assert torch.equal(a, im.step(torch.tensor(X), torch.tensor(U))[0])
-    assert emu_lib.cdll.od_set_cooperative(im._h, 3) == -1
+    assert emu_lib.cdll.od_set_cooperative(im._h, 4) == -1
 
 
 @pytest.mark.parametrize("name", COOP_MODELS)

@@ -12,15 +12,38 @@ def test_rollout_mappings_emulated(oracle, emu_lib):
     P.check_rollout_instantiation(oracle, emu_lib, "cpu", 37, 6, 16, n_oracle=37, t_chain=(0, 5))
 
 
+def test_rollout_eight_lane_form_emulated(oracle, emu_lib):
+    """the hopper through od_coop3.h (what batches of 4097..8192 run): forced on a small batch, against the 16-lane form"""
+    import torch
+    import workloads as W
+    x1, U = W.hopper_rollout_inputs(24, 8, seed=23, u_sigma=0.7)
+    im = P.make_im("hopper", emu_lib, "cpu")
+    outs = []
+    for mode in (2, 3):
+        im.set_cooperative(mode)
+        X, G, st, it, _ = im.rollout_compact(torch.tensor(x1), torch.tensor(U))
+        outs.append((X.clone(), st.clone(), it.clone()))
+        D, Gs, s1, i1 = im.step_grad_compact(X[:, 3].contiguous(), torch.tensor(U[:, 3]))
+        assert torch.equal(D, X[4:, 4]) and torch.equal(s1, st[3]) and torch.equal(i1, it[:, 3])       # rollout == chained steps
+    assert torch.equal(outs[0][1], outs[1][1]) and (outs[0][2] == outs[1][2]).double().mean().item() > 0.99
+    assert (outs[0][0] - outs[1][0]).abs().max().item() < 1e-8
+
+
 def test_plumbing_config_callbacks_emulated(oracle, emu_lib):
     P.check_plumbing_config_callbacks(oracle, emu_lib, "cpu")
 
 
 @pytest.mark.gpu
-def test_rollout_two_wavefronts_per_simd_build(oracle, gpu_lib):
-    """B = 8192 (BASELINE config 4 on one GPU): k_rollout_state_coop<COOP, 2>; reference mapping: the same trajectories
-    in two batches of 4096 through k_rollout_state_coop<COOP, 1>"""
-    P.check_rollout_instantiation(oracle, gpu_lib, "cuda:0", 8192, 20, 4096, t_chain=(0, 7, 19))
+def test_rollout_8192_eight_lanes_per_problem(oracle, gpu_lib):
+    """B = 8192 (BASELINE config 4 on one GPU): k_rollout_state_coop3<Coop3_hopper>, 1024 wavefronts of 8 problems; reference
+    mapping: the same trajectories in two batches of 4096 through the 16-lane kernel k_rollout_state_coop<Coop_hopper>"""
+    P.check_rollout_instantiation(oracle, gpu_lib, "cuda:0", 8192, 20, 4096, t_chain=(0, 7, 19), same_form=False)
+
+
+@pytest.mark.gpu
+def test_rollout_4100_eight_lanes_ragged(oracle, gpu_lib):
+    """B = 4100: the 8-lane form with a ragged last wavefront; reference: batches of 2050 through the 16-lane form (rpw = 4)"""
+    P.check_rollout_instantiation(oracle, gpu_lib, "cuda:0", 4100, 12, 2050, t_chain=(0, 11), same_form=False)
 
 
 @pytest.mark.gpu
