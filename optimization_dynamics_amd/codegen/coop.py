@@ -267,9 +267,10 @@ def _emit(m: ModelSpec, d: Derived) -> str:
     w("struct Coop_%s {\n" % n)
     w("  using M = Model_%s;\n" % n)
     w("  static constexpr int NQ = %d, NC = %d, NK = %d, SH = %d;\n" % (nq, NC, NK, SH))
-    w("  // chosen automatically for small batches only where the lanes have enough to share (measured: the hopper's 4 contacts\n")
-    w("  // + 2 cones halve the time of a rollout; the acrobot's 2 contacts do not pay for the replicated evaluation)\n")
-    w("  static constexpr bool AUTO = %s;\n" % ("true" if NC + NK >= 4 else "false"))
+    w("  // chosen automatically for small batches (csrc/od_model_tu.inc: up to 8192 problems with four or more contacts / cones to\n")
+    w("  // share out, up to 4096 with fewer -- the acrobot's two contacts pay through the row-private backtracking of a solve\n")
+    w("  // that jams: 65 536 knots of the joint-limit workload 0.40 ms against 1.20 lane-per-problem)\n")
+    w("  static constexpr bool AUTO = true;\n")
 
     def arr(name, xs, ty="int"):
         xs = list(xs) or [0]
@@ -299,6 +300,13 @@ def _emit(m: ModelSpec, d: Derived) -> str:
     w("  // replicated copies of the contact forces the dynamics rows (gather_r) / their Jacobian (gather_rz) read\n")
     gather("gather_r", fv_r, False)
     gather("gather_rz", fv_rz, True)
+    w("  // the same copies from per-role arrays (parallel line-search trials, od_coop.h::coop_trials_lanes)\n")
+    w("  template <class V> OD_HD static void scatter_r(const V* P0, const V* P1, const V* D0, const V* D1, V* zr) {\n")
+    for k in fv_r:
+        lane, fld = lane_of_z(k)
+        w("    zr[%d] = %s[%d];\n" % (k, fld, lane))
+    w("  }\n")
+    arr("E1ROW", e1_rows)
     w("  // aux-1 expression of the lane: -(phi_i) for contact i, the tangential velocity for cone c (rows of the serial\n")
     w("  // residual evaluated with s_i = s_b = 0)\n")
     w("  template <class RO, class L_> OD_HD static typename RO::V pick_e1(const L_& L, const double* rr) {\n")

@@ -48,9 +48,10 @@ inline Vec16& operator*=(Vec16& a, const Vec16& b) { a = a * b; return a; }
 #define OD_V16_CMP(op)                                                                                               \
   inline Mask16 operator op(const Vec16& a, const Vec16& b) { Mask16 r; for (int i = 0; i < 16; ++i) r.m[i] = a.v[i] op b.v[i]; return r; } \
   inline Mask16 operator op(const Vec16& a, double b) { Mask16 r; for (int i = 0; i < 16; ++i) r.m[i] = a.v[i] op b; return r; }
-OD_V16_CMP(>) OD_V16_CMP(<) OD_V16_CMP(!=)
+OD_V16_CMP(>) OD_V16_CMP(<) OD_V16_CMP(!=) OD_V16_CMP(<=) OD_V16_CMP(==)
 #undef OD_V16_CMP
 inline Mask16 operator&&(const Mask16& a, const Mask16& b) { Mask16 r; for (int i = 0; i < 16; ++i) r.m[i] = a.m[i] && b.m[i]; return r; }
+inline Mask16 operator!(const Mask16& a) { Mask16 r; for (int i = 0; i < 16; ++i) r.m[i] = !a.m[i]; return r; }
 inline Mask16 operator||(const Mask16& a, const Mask16& b) { Mask16 r; for (int i = 0; i < 16; ++i) r.m[i] = a.m[i] || b.m[i]; return r; }
 inline Vec16 od_rcp(const Vec16& a) { Vec16 r; for (int i = 0; i < 16; ++i) r.v[i] = od_rcp(a.v[i]); return r; }
 inline Vec16 od_rsqrt(const Vec16& a) { Vec16 r; for (int i = 0; i < 16; ++i) r.v[i] = od_rsqrt(a.v[i]); return r; }
@@ -94,6 +95,11 @@ struct RowEmu {
   static double vmin(double a, double b) { return od_fmin(a, b); }
   static bool first_lane() { return true; }
   static void arrived(const double&) {}
+  // parallel line-search trials: lane g of the row takes step alpha 2^-g
+  static V lane_ldexp(double a) { V r; for (int i = 0; i < 16; ++i) r.v[i] = od_ldexp(a, -i); return r; }
+  static B lane_below(int n) { B r; for (int i = 0; i < 16; ++i) r.m[i] = i < n; return r; }
+  static unsigned row_ballot(const B& b) { unsigned m = 0; for (int i = 0; i < 16; ++i) m |= (b.m[i] ? 1u : 0u) << i; return m; }
+  static double opaque(double x) { return x; }
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -155,6 +161,12 @@ struct RowDev {
   __device__ __forceinline__ static bool first_lane() { return lane() == 0; }
   // the value of an earlier load is needed from here on (places the s_waitcnt)
   __device__ __forceinline__ static void arrived(const double& x) { asm volatile("" ::"v"(x)); }
+  __device__ __forceinline__ static V lane_ldexp(double a) { return od_ldexp(a, -lane()); }
+  __device__ __forceinline__ static B lane_below(int n) { return lane() < n; }
+  // the 16 lanes' predicate bits of this row (under divergence: of the rows that execute)
+  __device__ __forceinline__ static unsigned row_ballot(bool b) { return (unsigned)(__builtin_amdgcn_ballot_w64(b) >> (threadIdx.x & 48)) & 0xFFFFu; }
+  // a constant the compiler must treat as a run-time value (keeps an expression's shape, hence its FMA contraction)
+  __device__ __forceinline__ static double opaque(double x) { asm volatile("" : "+v"(x)); return x; }
 };
 #endif
 
@@ -557,6 +569,87 @@ OD_HD double coop_centering(const CoopLanes<CM, RO>& L, const CoopVec<CM::NQ, ty
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Sixteen line-search trials at once: lane g of the row evaluates r(z - a_g D; theta, 0) for ITS step a_g = alpha 2^-g --
+// the whole residual in one lane, every contact and cone in turn, with the arithmetic of coop_eval_r / coop_viol (the
+// same generated eval_r on the same replicated z, the same row formulas; the maxima are order independent), so that a
+// trial is accepted here exactly when the cooperative evaluation of the same step accepts it.
+// ---------------------------------------------------------------------------------------------------------------
+template <class CM, class RO, int R = 0>
+OD_HD void coop_fetch_roles(const CoopVec<CM::NQ, typename RO::V>& z, typename RO::V* P0, typename RO::V* P1, typename RO::V* D0, typename RO::V* D1) {
+  if constexpr (R < CM::NC + CM::NK) {
+    using V = typename RO::V;
+    P0[R] = V(RO::template bc<R>(z.P0)); P1[R] = V(RO::template bc<R>(z.P1));
+    D0[R] = V(RO::template bc<R>(z.D0)); D1[R] = V(RO::template bc<R>(z.D1));
+    coop_fetch_roles<CM, RO, R + 1>(z, P0, P1, D0, D1);
+  }
+}
+
+template <class CM, class RO>
+OD_HD typename RO::B coop_trials_lanes(const CoopLanes<CM, RO>& L, const double* th, const double* pre, const CoopVec<CM::NQ, typename RO::V>& z,
+                                       const CoopVec<CM::NQ, typename RO::V>& D, typename RO::V aj, double r_vio, double k_vio) {
+  using M = typename CM::M;
+  using V = typename RO::V;
+  constexpr int NQ = CM::NQ, NR = (CM::NC + CM::NK) > 0 ? (CM::NC + CM::NK) : 1;
+  const double inf = __builtin_inf();
+  V zP0[NR], zP1[NR], zD0[NR], zD1[NR], dP0[NR], dP1[NR], dD0[NR], dD1[NR];
+  coop_fetch_roles<CM, RO>(z, zP0, zP1, zD0, zD1);
+  coop_fetch_roles<CM, RO>(D, dP0, dP1, dD0, dD1);
+  V zr[M::NZ], rr[M::NZ], thv[M::NTH], prev[M::NPRE], trv[M::NTR];
+#pragma unroll
+  for (int i = 0; i < M::NZ; ++i) zr[i] = V(0.0);
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) zr[CM::ZQ[k]] = V(z.q[k]) - aj * V(D.q[k]);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    zP0[i] = zP0[i] - aj * dP0[i]; zP1[i] = zP1[i] - aj * dP1[i];
+    zD0[i] = zD0[i] - aj * dD0[i]; zD1[i] = zD1[i] - aj * dD1[i];
+  }
+  CM::scatter_r(zP0, zP1, zD0, zD1, zr);
+#pragma unroll
+  for (int i = 0; i < M::NTH; ++i) thv[i] = V(th[i]);
+#pragma unroll
+  for (int i = 0; i < M::NPRE; ++i) prev[i] = V(pre[i]);
+  M::eval_r(zr, thv, prev, trv, rr);
+  V ve = V(0.0), se = V(0.0);
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) { const V a = od_abs(rr[CM::RDYN[k]]); ve = od_fmax(ve, a); se = se + a; }
+  double g[CM::NK > 0 ? CM::NK : 1], gc[CM::NK > 0 ? CM::NK : 1];
+  if constexpr (CM::NK > 0) CM::eval_gcoef(th, g, gc);
+  V de = V(0.0), dk = V(0.0);
+#pragma unroll
+  for (int i = 0; i < CM::NC + CM::NK; ++i) {
+    const bool cone = i >= CM::NC;
+    const double c_s = RO::opaque(cone ? 0.0 : 1.0), c_v = RO::opaque(CM::CV[i]);
+    const V r1 = rr[CM::E1ROW[i]] + c_s * zD0[i] + c_v * zD1[i];
+    V r2 = V(0.0);
+    if constexpr (CM::NK > 0) {
+      if (cone) {
+        const int c = i - CM::NC;
+        const double c_psi = RO::opaque(1.0);
+        const V gp = (CM::SH > 0 && i - CM::SH >= 0) ? zP0[i - CM::SH >= 0 ? i - CM::SH : 0] : V(0.0);
+        r2 = c_psi * zP0[i] + V(g[c]) * gp + V(gc[c]);
+      }
+    }
+    const V rA = zP0[i] * zD0[i] + zP1[i] * zD1[i];
+    const V rB = zP0[i] * zD1[i] + zP1[i] * zD0[i];
+    const V a1 = od_abs(r1), a2 = od_abs(r2), aA = od_abs(rA), aB = od_abs(rB);
+    V e = od_fmax(a1, a2);
+    const V es = a1 + a2;
+    e = RO::sel(es != es, inf, e);
+    V k = od_fmax(aA, aB);
+    const V ks = aA + aB;
+    k = RO::sel(ks != ks, inf, k);
+    de = RO::vmax(de, e);
+    dk = RO::vmax(dk, k);
+  }
+  de = RO::vmax(de, ve);
+  // NaN-sticky violations (coop_viol): a NaN fails both comparisons
+  const typename RO::B r_nan = (se != se) || (de == inf), k_nan = (dk == inf);
+  const typename RO::B r_ok = (de <= r_vio) && !r_nan, k_ok = (dk <= k_vio) && !k_nan;
+  return r_ok || k_ok;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // one predictor-corrector iteration (od_solver.h::ip_iteration), line search included
 // ---------------------------------------------------------------------------------------------------------------
 template <class CM, class RO>
@@ -587,19 +680,45 @@ OD_HD void coop_iteration(const CoopLanes<CM, RO>& L, const Opts<double>& o, con
   const double vio = RO::vmax(r_vio, k_vio);
   const double tau = 1.0 - od_fmin(o.eps_min, vio * vio);
   double alpha = coop_step_length<CM, RO>(L, sp, D, tau, od_fmin(tau, 0.99));
-  // backtracking until either violation does not increase (od_solver.h::line_search, sequential form)
-  Vec zc;
-  Res rc;
-  double r_c = 0.0, k_c = 0.0;
-  for (int ls = 0; ls < o.max_ls; ++ls) {
+  // backtracking until either violation does not increase (od_solver.h::line_search): two trials one after the other,
+  // then -- a solve that jams spends most of its time here, ~8 trials in each of its 100 iterations -- the 16 lanes of the
+  // row each try a step size (coop_trials_lanes), agree on the first accepted one (the one the sequential loop would
+  // find) and the row re-evaluates that one in its cooperative form: same iterates, bit for bit
+  Vec zc = z;
+  Res rc = r;
+  double r_c = r_vio, k_c = k_vio;
+  auto trial = [&](double a) {
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) zc.q[k] = z.q[k] - alpha * D.q[k];
-    zc.P0 = z.P0 - alpha * D.P0; zc.P1 = z.P1 - alpha * D.P1;
-    zc.D0 = z.D0 - alpha * D.D0; zc.D1 = z.D1 - alpha * D.D1;
+    for (int k = 0; k < NQ; ++k) zc.q[k] = z.q[k] - a * D.q[k];
+    zc.P0 = z.P0 - a * D.P0; zc.P1 = z.P1 - a * D.P1;
+    zc.D0 = z.D0 - a * D.D0; zc.D1 = z.D1 - a * D.D1;
     coop_eval_r<CM, RO>(L, zc, th, pre, tr, rc);
     coop_viol<CM, RO>(L, rc, r_c, k_c);
-    if (r_c <= r_vio || k_c <= k_vio) break;
+    return r_c <= r_vio || k_c <= k_vio;
+  };
+  const int nseq = o.max_ls < 2 ? o.max_ls : 2;
+  bool done = false;
+  int ls = 0;
+  for (; ls < nseq; ++ls) {
+    if (trial(alpha)) { done = true; break; }
     if (ls + 1 < o.max_ls) alpha *= 0.5;
+  }
+  if (!done && ls < o.max_ls) {
+    // alpha is the step of trial `ls`; the lanes try trials j0 .. j0 + 15
+    bool found = false;
+    for (int j0 = ls; j0 < o.max_ls && !found; j0 += 16) {
+      const typename RO::B acc = coop_trials_lanes<CM, RO>(L, th, pre, z, D, RO::lane_ldexp(alpha), r_vio, k_vio) && RO::lane_below(o.max_ls - j0);
+      const unsigned m = RO::row_ballot(acc);
+      if (m != 0) {
+        alpha = od_ldexp(alpha, -__builtin_ctz(m));                      // first accepted trial of the round
+        found = true;
+      } else {
+        const int left = o.max_ls - 1 - j0;                              // trials after j0: move on by 16, or to the last
+        alpha = od_ldexp(alpha, -(left < 16 ? left : 16));
+        if (left < 16) break;                                            // alpha is now the last trial's step
+      }
+    }
+    trial(alpha);                                                        // the row lands on the chosen trial
   }
   z = zc;
   r = rc;
