@@ -405,6 +405,7 @@ struct od_handle_s {
   int coop;        // cooperative state kernels (od_coop.h): 0 automatic, 1 never, 2 wherever the model has them
   double* work;    // device workspace: gradient iterates handed from pass 1 to pass 2
   size_t work_elems;
+  long grad_knots; // knots of the last gradient pass (the hand-over is batch-minor with that stride); 0 = none
   double* stage;   // device staging for the host scalar path
   size_t stage_elems;
 };
@@ -506,6 +507,7 @@ int check_mech(od_handle_s* h, const char* fn) {
 
 // pass 2 over K knots whose states live in `xstate` (slot k) -- shared by od_step_grad and od_rollout
 int run_grad_pass(od_handle_s* h, StepArgs<double> g, long K, View<const double> xstate) {
+  h->grad_knots = K;
   g.B = K;
   g.x = xstate;
   g.d.p = nullptr;
@@ -726,6 +728,7 @@ int od_create(int model, int dtype, const od_options* opts, double dt, od_handle
   h->wpb = 0;
   h->work = nullptr;
   h->work_elems = 0;
+  h->grad_knots = 0;
   h->stage = nullptr;
   h->stage_elems = 0;
   *out = h;
@@ -775,9 +778,16 @@ int od_set_stream(od_handle h, void* s) {
   if (!h) return fail(OD_ERR_INVALID, "od_set_stream: null handle");
   if (h->stream != (hipStream_t)s) {
     // the handle's workspaces (gradient hand-over, staging) are shared by consecutive calls: a handle works on one
-    // stream at a time, so work queued on the old stream finishes before the new one may reuse them
-    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(OD_ERR_HIP, "od_set_stream: hipStreamSynchronize of the previous stream failed");
+    // stream at a time, so work queued on the old stream finishes before the new one may reuse them.  If the old stream
+    // cannot be synchronised (the caller destroyed it), the device is synchronised instead and the new stream is adopted
+    // all the same -- the handle must not stay tied to a dead stream; the failure is still reported.
+    const hipError_t e = hipStreamSynchronize(h->stream);
     h->stream = (hipStream_t)s;
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipDeviceSynchronize();
+      return fail(OD_ERR_HIP, std::string("od_set_stream: the previous stream could not be synchronised (") + hipGetErrorString(e) + "); the new stream is in use");
+    }
   }
   return OD_OK;
 }
@@ -790,7 +800,8 @@ int od_set_cooperative(od_handle h, int mode) {
 int od_get_grad_iterates(od_handle h, long K, void* out) {
   if (!h || !out || K <= 0) return fail(OD_ERR_INVALID, "od_get_grad_iterates: null handle / buffer");
   const size_t n = (size_t)(h->vt->nz + 1) * (size_t)K;
-  if (!h->work || h->work_elems < n) return fail(OD_ERR_INVALID, "od_get_grad_iterates: no gradient pass over that many knots has run on this handle");
+  if (!h->work || h->work_elems < n || h->grad_knots != K)
+    return fail(OD_ERR_INVALID, "od_get_grad_iterates: K must be the number of knots of the last gradient pass on this handle (" + std::to_string(h->grad_knots) + ")");
   OD_HIP(hipMemcpyAsync(out, h->work, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   return OD_OK;
 }
@@ -991,6 +1002,7 @@ int od_ls_fit(od_handle h, long B, int N, int ny, int nzb, const void* eta, cons
     return fail(OD_ERR_INVALID, "od_ls_fit: bad arguments (ny, nzb <= 24)");
   View<const double> fv = mkcview<double>(feta, ny, (long)(N + 1) * B, OD_LAYOUT_BATCH_MINOR);
   if (int rc = ensure_work(h, (size_t)nzb * (nzb + ny) * (size_t)B)) return rc;
+  h->grad_knots = 0;                                   // the workspace no longer holds gradient iterates
   return run_ls(h, B, N, ny, nzb, (const double*)eta, fv, h->work, M, status);
 }
 
@@ -1146,36 +1158,63 @@ static int ensure_stage(od_handle_s* h, size_t elems) {
 
 // f_rocket / fx_rocket / fu_rocket (project = 0) and the *_proj variants (project = 1) for one (x, u) on host vectors
 // (src/models/rocket/dynamics.jl:101-164, 215-268); y 12, dx 12 x 12, du 12 x 3, uproj 3 (col-major); outputs may be NULL
-int od_rocket_host(od_handle h, int project, const double* x, const double* u, double* y, double* dx, double* du, double* uproj, int* status) {
-  if (!h || !x || !u) return fail(OD_ERR_INVALID, "od_rocket_host: null argument");
+// (an OD_F32 handle computes in float: the host doubles are converted on the way in and out -- the staging area holds
+// elements of the handle's type)
+extern "C++" {
+template <class T> static int rocket_host_impl(od_handle h, int project, const double* x, const double* u, double* y, double* dx, double* du, double* uproj, int* status) {
   if (int rc = ensure_stage(h, 12 + 3 + 12 + 144 + 36 + 3 + 1)) return rc;
-  double* px = h->stage; double* pu = px + 12; double* py = pu + 3; double* pdx = py + 12; double* pdu = pdx + 144; double* pup = pdu + 36;
-  int* pst = (int*)(pup + 3);
-  OD_HIP(hipMemcpyAsync(px, x, 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  OD_HIP(hipMemcpyAsync(pu, u, 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  T* px = (T*)h->stage; T* pu = px + 12; T* py = pu + 3; T* pdx = py + 12; T* pdu = pdx + 144; T* pup = pdu + 36;
+  int* pst = (int*)((double*)h->stage + 12 + 3 + 12 + 144 + 36 + 3);
+  T hx[15];
+  for (int i = 0; i < 12; ++i) hx[i] = (T)x[i];
+  for (int i = 0; i < 3; ++i) hx[12 + i] = (T)u[i];
+  OD_HIP(hipMemcpyAsync(px, hx, 15 * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  OD_HIP(hipStreamSynchronize(h->stream));      // hx lives on this stack frame
   if (int rc = od_rocket(h, 1, project, px, pu, py, dx ? pdx : nullptr, du ? pdu : nullptr, pup, pst)) return rc;
-  if (y) OD_HIP(hipMemcpyAsync(y, py, 12 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (dx) OD_HIP(hipMemcpyAsync(dx, pdx, 144 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (du) OD_HIP(hipMemcpyAsync(du, pdu, 36 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (uproj && project) OD_HIP(hipMemcpyAsync(uproj, pup, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  T out[12 + 144 + 36 + 3];
+  OD_HIP(hipMemcpyAsync(out, py, sizeof(out), hipMemcpyDeviceToHost, h->stream));
   if (status) OD_HIP(hipMemcpyAsync(status, pst, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   OD_HIP(hipStreamSynchronize(h->stream));
+  if (y) for (int i = 0; i < 12; ++i) y[i] = (double)out[i];
+  if (dx) for (int i = 0; i < 144; ++i) dx[i] = (double)out[12 + i];
+  if (du) for (int i = 0; i < 36; ++i) du[i] = (double)out[12 + 144 + i];
+  if (uproj && project) for (int i = 0; i < 3; ++i) uproj[i] = (double)out[12 + 144 + 36 + i];
   return OD_OK;
 }
 
+}  // extern "C++"
+
+int od_rocket_host(od_handle h, int project, const double* x, const double* u, double* y, double* dx, double* du, double* uproj, int* status) {
+  if (!h || !x || !u) return fail(OD_ERR_INVALID, "od_rocket_host: null argument");
+  if (h->dtype == OD_F32) return rocket_host_impl<float>(h, project, x, u, y, dx, du, uproj, status);
+  return rocket_host_impl<double>(h, project, x, u, y, dx, du, uproj, status);
+}
+
 // soc_projection (duproj = NULL) / soc_projection_gradient for one u on host vectors (dynamics.jl:168-214)
-int od_soc_project_host(od_handle h, const double* u, double* uproj, double* duproj, int* status) {
-  if (!h || !u) return fail(OD_ERR_INVALID, "od_soc_project_host: null argument");
+extern "C++" {
+template <class T> static int soc_project_host_impl(od_handle h, const double* u, double* uproj, double* duproj, int* status) {
   if (int rc = ensure_stage(h, 3 + 3 + 9 + 1)) return rc;
-  double* pu = h->stage; double* pup = pu + 3; double* pd = pup + 3;
-  int* pst = (int*)(pd + 9);
-  OD_HIP(hipMemcpyAsync(pu, u, 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  T* pu = (T*)h->stage; T* pup = pu + 3; T* pd = pup + 3;
+  int* pst = (int*)((double*)h->stage + 3 + 3 + 9);
+  T hu[3] = {(T)u[0], (T)u[1], (T)u[2]};
+  OD_HIP(hipMemcpyAsync(pu, hu, sizeof(hu), hipMemcpyHostToDevice, h->stream));
+  OD_HIP(hipStreamSynchronize(h->stream));
   if (int rc = od_soc_project(h, 1, pu, pup, duproj ? pd : nullptr, pst)) return rc;
-  if (uproj) OD_HIP(hipMemcpyAsync(uproj, pup, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (duproj) OD_HIP(hipMemcpyAsync(duproj, pd, 9 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  T out[12];
+  OD_HIP(hipMemcpyAsync(out, pup, sizeof(out), hipMemcpyDeviceToHost, h->stream));
   if (status) OD_HIP(hipMemcpyAsync(status, pst, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   OD_HIP(hipStreamSynchronize(h->stream));
+  if (uproj) for (int i = 0; i < 3; ++i) uproj[i] = (double)out[i];
+  if (duproj) for (int i = 0; i < 9; ++i) duproj[i] = (double)out[3 + i];
   return OD_OK;
+}
+
+}  // extern "C++"
+
+int od_soc_project_host(od_handle h, const double* u, double* uproj, double* duproj, int* status) {
+  if (!h || !u) return fail(OD_ERR_INVALID, "od_soc_project_host: null argument");
+  if (h->dtype == OD_F32) return soc_project_host_impl<float>(h, u, uproj, duproj, status);
+  return soc_project_host_impl<double>(h, u, uproj, duproj, status);
 }
 
 // gradient!(sim, gb, q1, q2, u1) for one knot on host vectors (src/gradient_bundle.jl:87-104): x = [q1; q2], eta

@@ -142,10 +142,20 @@ class ILQR:
                 quad = obj.expansion(X, U, lam, rho)
                 K, k, dV, bst = self.backward(A, Bm, quad, reg)
                 # a backward pass whose Quu + reg I was not positive definite clamps its pivot and returns useless gains:
-                # raise the regularisation and repeat it before spending a forward pass on them
-                while (bst != 1).any() and reg < 1e6:
-                    reg = min(max(reg, 1e-8) * 10.0, 1e6)
-                    K, k, dV, bst = self.backward(A, Bm, quad, reg)
+                # raise the regularisation and repeat it before spending a forward pass on them -- for THOSE trajectories
+                # only (the batch shares `reg`, but one persistently bad trajectory, e.g. a non-finite linearisation from a
+                # failed contact solve, must not cripple the gains of the others or end the whole batch at reg = 1e6)
+                bad = (bst != 1)
+                reg_b = reg
+                while bad.any() and reg_b < 1e6:
+                    reg_b = min(max(reg_b, 1e-8) * 10.0, 1e6)
+                    idx = bad.nonzero().flatten()
+                    Ks, ks, dVs, bs = self.backward(A[..., idx], Bm[..., idx], tuple(q[..., idx].contiguous() for q in quad), reg_b)
+                    K[..., idx] = Ks; k[..., idx] = ks; dV[:, idx] = dVs
+                    bad = torch.zeros_like(bad)
+                    bad[idx[bs != 1]] = True
+                if bad.any():        # still not factorisable (non-finite data): no step for these, the line search rejects them
+                    K[..., bad] = 0.0; k[..., bad] = 0.0; dV[:, bad] = 0.0
                 Xc, Uc, cst = self.forward(x1, X, U, K, k)
                 Jc = obj.value(Xc, Uc, None if lam is None else lam.repeat(1, na), rho).view(na, B)
                 ok_roll = ((cst & 1) == 1).all(0).view(na, B)

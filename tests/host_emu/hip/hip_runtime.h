@@ -37,6 +37,7 @@ inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return hi
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 
 // ---- lockstep rows (od_emu_set_lockstep(1)): the 16 threads of a DPP row run as 16 host threads that meet at every
 // cross-lane operation, so the lane cooperation of od_solver.h (row rotations between the copies of a problem: shared

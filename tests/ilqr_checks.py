@@ -76,6 +76,19 @@ def check_solver_decreases_cost(lib, device, B=8, T=25):
     return J0, Jf
 
 
+def check_one_bad_trajectory_does_not_hurt_the_batch(lib, device, B=4, T=20):
+    """a trajectory whose linearisation is not finite (NaN control: a failed contact solve looks the same) keeps its backward
+    pass from factorising at any regularisation; the others must converge exactly as they do without it"""
+    im, obj, x1, U0 = cartpole_problem(lib, device, B, T, seed=1)
+    x1t = torch.tensor(x1, device=device)
+    good = IL.ILQR(im, obj, T).solve(x1t, torch.tensor(U0, device=device), max_iter=8, max_al_iter=1)
+    U0b = U0.copy(); U0b[:, 3, 1] = np.nan
+    bad = IL.ILQR(im, obj, T).solve(x1t, torch.tensor(U0b, device=device), max_iter=8, max_al_iter=1)
+    keep = [0, 2, 3]
+    assert torch.isfinite(bad[2][keep]).all()
+    assert torch.equal(bad[1][:, :, keep], good[1][:, :, keep]) and torch.equal(bad[2][keep], good[2][keep])
+
+
 def rocket_problem(lib, device, B, T, dtype=torch.float64, seed=0):
     """rocket soft landing with the thrust-cone projection on the path (examples/rocket.jl:15-50 sizes:
     h=0.05, u_max=12.5); quadratic costs"""

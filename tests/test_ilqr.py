@@ -14,6 +14,15 @@ def test_solver_decreases_cost_cpu(emu_lib):
     C.check_solver_decreases_cost(emu_lib, "cpu", B=4, T=20)
 
 
+def test_one_bad_trajectory_does_not_hurt_the_batch_cpu(emu_lib):
+    C.check_one_bad_trajectory_does_not_hurt_the_batch(emu_lib, "cpu")
+
+
+@pytest.mark.gpu
+def test_one_bad_trajectory_does_not_hurt_the_batch_gpu(gpu_lib):
+    C.check_one_bad_trajectory_does_not_hurt_the_batch(gpu_lib, "cuda:0", B=16, T=30)
+
+
 @pytest.mark.gpu
 def test_backward_forward_gpu(oracle, gpu_lib):
     C.check_backward_and_forward(oracle, gpu_lib, "cuda:0")

@@ -105,3 +105,45 @@ def test_rocket_sequence(oracle, emu_lib):
     assert np.abs(up - z[:3]).max() < 2e-4 * max(1, np.abs(z[:3]).max())
     assert np.hypot(up[0], up[1]) <= up[2] + 2e-2            # examples/rocket.jl:151
     assert emu_lib.cdll.od_destroy(hd) == 0
+
+
+def test_rocket_host_entry_points_on_a_single_precision_handle(emu_lib):
+    """od_rocket_host / od_soc_project_host take and return host DOUBLES whatever the handle computes in: on an OD_F32 handle
+    the values are converted on the way in and out (they used to be reinterpreted: garbage with rc = 0)"""
+    from optimization_dynamics_amd import models, rocket as rk
+    hd = C.c_void_p()
+    assert emu_lib.cdll.od_create(5, 1, None, C.c_double(0.05), C.byref(hd)) == 0        # OD_F32
+    assert emu_lib.cdll.od_set_u_max(hd, C.c_double(12.5)) == 0
+    from optimization_dynamics_amd._lib import Options
+    oo = Options()
+    assert emu_lib.cdll.od_get_options(hd, C.byref(oo)) == 0
+    oo.r_tol = 1e-4                                                                      # tolerances reachable in float (DESIGN.md 3.6)
+    assert emu_lib.cdll.od_set_options(hd, C.byref(oo)) == 0
+    Xr, Ur = W.rocket_inputs(3, seed=1)
+    info64 = rk.RocketInfo(models.rocket, 12.5, 0.05, device="cpu", lib=emu_lib)
+    for project in (0, 1):
+        Y, DX, DU, UP, st = info64.solve(torch.tensor(Xr), torch.tensor(Ur), project=bool(project), grads=True)
+        for b in range(3):
+            x, u = np.ascontiguousarray(Xr[:, b]), np.ascontiguousarray(Ur[:, b])
+            y = np.zeros(12); dx = np.zeros((12, 12), order="F"); du = np.zeros((12, 3), order="F"); up = np.zeros(3)
+            stat = C.c_int(0)
+            assert emu_lib.cdll.od_rocket_host(hd, project, _p(x), _p(u), _p(y), _p(dx), _p(du), _p(up), C.byref(stat)) == 0
+            assert np.isfinite(y).all() and np.abs(y - Y[:, b].numpy()).max() < 5e-4 * max(1.0, np.abs(Y[:, b].numpy()).max())
+            assert np.abs(dx - DX[:, :, b].numpy()).max() < 2e-2 * np.abs(DX[:, :, b].numpy()).max()
+            if project:
+                assert np.abs(up - UP[:, b].numpy()).max() < 5e-3 * max(1.0, np.abs(UP[:, b].numpy()).max())
+    up = np.zeros(3); dp = np.zeros((3, 3), order="F")
+    u = np.ascontiguousarray(Ur[:, 0])
+    assert emu_lib.cdll.od_soc_project_host(hd, _p(u), _p(up), _p(dp), None) == 0
+    assert np.isfinite(up).all() and np.isfinite(dp).all() and np.hypot(up[0], up[1]) <= up[2] + 2e-2
+    assert emu_lib.cdll.od_destroy(hd) == 0
+
+
+def test_grad_iterates_need_the_knot_count_of_the_last_pass(emu_lib):
+    im = P.make_im("hopper", emu_lib, "cpu")
+    X, U = W.knots("hopper", 12, seed=3)
+    im.step_grad(torch.tensor(X), torch.tensor(U))
+    assert im.grad_iterates(12).shape == (21, 12)
+    buf = torch.empty(21 * 8, dtype=torch.float64)
+    assert emu_lib.cdll.od_get_grad_iterates(im._h, 8, buf.data_ptr()) == -1          # another K: wrong stride, refused
+    assert b"last gradient pass" in emu_lib.cdll.od_last_error()
