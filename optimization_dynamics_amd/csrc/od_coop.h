@@ -752,6 +752,25 @@ OD_HD int coop_ip_step(const CoopLanes<CM, RO>& L, const Opts<double>& o, const 
     const bool last = it >= o.max_iter;
     if (!grad_done && ((req && k_vio < o.kappa_grad) || last)) {
       defer(z, od_max(reg_prev, o.kappa_grad * o.gamma_reg));
+#ifdef OD_EXPERIMENT_FUSED_GRAD_COST
+      // MEASUREMENT ONLY (tools/build_variants.sh; never in the shipped library): what a gradient fused into the cooperative
+      // row would put on the trajectory's critical path -- one pivoted factorisation at the gradient iterate and 2nq + nu
+      // cooperative back-solves (a stand-in right-hand side; the 319-operation rtheta evaluation is not even counted).
+      {
+        CoopFact<CM, RO> fg;
+        if (!coop_eval_factor<CM, true, RO>(L, z, th, pre, tr, od_max(reg_prev, o.kappa_grad * o.gamma_reg), fg)) status &= ~OD_ST_FACTOR_OK;
+        CoopVec<NQ, V> xg;
+        CoopRes<NQ, V> rg = r;
+        double accg = 0.0;
+        for (int c = 0; c < 2 * NQ + CM::M::NU; ++c) {
+          rg.rd[c % NQ] += 1.0;
+          coop_solve<CM, true, RO>(L, fg, z, rg, xg);
+#pragma unroll
+          for (int k = 0; k < NQ; ++k) accg += xg.q[k];
+        }
+        if (accg == 1.2345e300) status |= 64;          // keeps the work alive
+      }
+#endif
       grad_done = true;
       iters[1] = it;
       if (!last) status |= OD_ST_GRAD_OK;

@@ -45,9 +45,25 @@ if os.path.exists(os.path.join(src, "pmc_sq2", "p_counter_collection.csv")):
                % (100 * s2["SQ_ACTIVE_INST_SCA"] / s["SQ_WAVE_CYCLES"], 100 * s2["SQ_ACTIVE_INST_MISC"] / s["SQ_WAVE_CYCLES"], s2["SQ_INSTS_VMEM"] / 1e3))
 sys.path.insert(0, ROOT)
 import bench
-json.dump({"tag": tag, "workload": "bench.py default (hopper T=100 batch=4096, od_rollout_compact)", "hbm_bytes_per_step": tot,
-           "formula": "2*FETCH_SIZE + WRITE_SIZE [KB*1024] over k_rollout_state* and k_grad_knots, mean per dispatch",
-           "source_hash": bench.kernel_source_hash()}, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
+rec = {"tag": tag, "workload": "bench.py default (hopper T=100 batch=4096, od_rollout_compact)", "hbm_bytes_per_step": tot,
+       "formula": "2*FETCH_SIZE + WRITE_SIZE [KB*1024] over k_rollout_state* and k_grad_knots, mean per dispatch",
+       "source_hash": bench.kernel_source_hash()}
+# executed (not algorithmic) fp64 work: wavefront-level instruction counts of the fp64 arithmetic classes; one wavefront
+# instruction occupies 64 lane slots of the SIMD whatever its lanes hold (a cooperative row has 6 role lanes + their mirrors)
+rec["valu_issue_util"] = s["SQ_ACTIVE_INST_VALU"] / s["SQ_WAVE_CYCLES"]
+rec["valu_insts_per_step"] = s["SQ_INSTS_VALU"] + m["k_grad_knots"]["SQ_INSTS_VALU"]
+if os.path.exists(os.path.join(src, "pmc_f64", "p_counter_collection.csv")):
+    mf, _ = per_kernel("pmc_f64")
+    tot_f = {c: sum(mf[k].get(c, 0.0) for k in mf) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU")}
+    wave_flops = tot_f["SQ_INSTS_VALU_ADD_F64"] + tot_f["SQ_INSTS_VALU_MUL_F64"] + 2.0 * tot_f["SQ_INSTS_VALU_FMA_F64"]
+    rec["fp64_wave_instructions_per_step"] = {k: v for k, v in tot_f.items() if k.endswith("F64")}
+    rec["executed_lane_slot_flops_per_step"] = 64.0 * wave_flops          # what the SIMDs spend
+    rec["active_lane_fraction"] = tot_f["SQ_THREAD_CYCLES_VALU"] / (64.0 * tot_f["SQ_ACTIVE_INST_VALU"]) if tot_f["SQ_ACTIVE_INST_VALU"] else None
+    rec["fp64_fraction_of_valu_instructions"] = (tot_f["SQ_INSTS_VALU_ADD_F64"] + tot_f["SQ_INSTS_VALU_MUL_F64"] + tot_f["SQ_INSTS_VALU_FMA_F64"] + tot_f["SQ_INSTS_VALU_TRANS_F64"]) / tot_f["SQ_INSTS_VALU"]
+    out.append("fp64 arithmetic, wavefront-level instructions per step (both kernels): %s; %.1f %% of the VALU instructions; x 64 lanes = %.3e executed lane-slot flops per step (%.0f per unit); active lanes %.0f %%"
+               % (json.dumps({k: int(v) for k, v in rec["fp64_wave_instructions_per_step"].items()}), 100 * rec["fp64_fraction_of_valu_instructions"],
+                  rec["executed_lane_slot_flops_per_step"], rec["executed_lane_slot_flops_per_step"] / 409600.0, 100 * (rec["active_lane_fraction"] or 0)))
+json.dump(rec, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
 notes = os.path.join(dst, tag + "_pmc_notes.txt")
 if os.path.exists(notes):
     out.append("")
