@@ -319,7 +319,7 @@ def main():
     it_max = int(it.max().item())
 
     latency_floor_ms = dense_ms = None
-    if rank == 0 and world == 1 and not emu:
+    if rank == 0 and world == 1 and not emu and not args.no_cpu_baseline:      # (--no-cpu-baseline = the bare timed region: profiling passes)
         # the latency of ONE trajectory's T sequential knots (64 rollouts: one per wavefront, the chip nearly empty): no batch
         # of any size finishes a step faster than this; and the same step writing the dense fx / fu (od_rollout)
         xs, Us = workload_slice(0, 64, args.batch, T)

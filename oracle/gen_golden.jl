@@ -13,6 +13,8 @@
 #     out: <model>_D.bin (2nq x B), <model>_DX.bin (2nq x 2nq x B), <model>_DU.bin (2nq x nu x B),
 #          <model>_IT.bin (3 x B: interior-point iterations of the f, fx and fu solves; -1 if the field is not there),
 #          <model>_ST.bin (3 x B: 1 = the solver reported success, 0 = failure, -1 = not observable)
+#          <model>_ZG.bin (nz x B: the iterate z the fx solve differentiated at -- grad_sim.ip.z --, NaN if not observable;
+#                          lets the comparison arbitrate ill-conditioned gradients in binary128, tests/test_reference_golden.py)
 #   rocket (src/models/rocket/dynamics.jl:101-268), u_max = 12.5, h = 0.05 (examples/rocket.jl:16,19)
 #     in : rocket_X.bin (12 x B), rocket_U.bin (3 x B)
 #     out: rocket_Y.bin, rocket_DX.bin (12 x 12 x B), rocket_DU.bin (12 x 3 x B)            f/fx/fu_rocket
@@ -53,10 +55,14 @@ function run_mech(name, im_dyn, nq, nu)
     U = readmat(joinpath(indir, name * "_U.bin"), nu)
     B = size(X, 2)
     D = zeros(2nq, B); DX = zeros(2nq, 2nq, B); DU = zeros(2nq, nu, B); IT = fill(-1.0, 3, B); ST = fill(-1.0, 3, B)
+    ipg = ip_of(im_dyn.grad_sim)
+    nz = (ipg !== nothing && hasproperty(ipg, :z)) ? length(ipg.z) : 0
+    ZG = fill(NaN, max(nz, 1), B)
     for b = 1:B
         d = zeros(2nq); dx = zeros(2nq, 2nq); du = zeros(2nq, nu)
         f(d, im_dyn, X[:, b], U[:, b], zeros(0));   IT[1, b] = iters_of(im_dyn.eval_sim); ST[1, b] = status_of(im_dyn.eval_sim)
         fx(dx, im_dyn, X[:, b], U[:, b], zeros(0)); IT[2, b] = iters_of(im_dyn.grad_sim); ST[2, b] = status_of(im_dyn.grad_sim)
+        nz > 0 && (ZG[:, b] .= ipg.z)
         fu(du, im_dyn, X[:, b], U[:, b], zeros(0)); IT[3, b] = iters_of(im_dyn.grad_sim); ST[3, b] = status_of(im_dyn.grad_sim)
         D[:, b] = d; DX[:, :, b] = dx; DU[:, :, b] = du
     end
@@ -65,6 +71,7 @@ function run_mech(name, im_dyn, nq, nu)
     writearr(joinpath(outdir, name * "_DU.bin"), DU)
     writearr(joinpath(outdir, name * "_IT.bin"), IT)
     writearr(joinpath(outdir, name * "_ST.bin"), ST)
+    nz > 0 && writearr(joinpath(outdir, name * "_ZG.bin"), ZG)
 end
 
 # gradient! with the exported eta.  The constructor sizes q1η / q2η / u1η with the module globals nq, nu (the rocket's

@@ -38,23 +38,30 @@ def make_sim(oracle, name, **over):
 
 
 def assert_grad_close(G, Go, ok, what):
-    """statistical form, for comparisons without recorded iterates (see module docstring)"""
+    """statistical form, for comparisons without recorded iterates (see module docstring): 1e-4 on >= 99.8 % of the knots,
+    1e-9 median, and a finite cap on the rest -- the largest exact movement of a gradient between two iterates inside r_tol
+    seen in 1.2 million arbitrated knots is 7e-2 (profiles/r2_parity_soak.json); anything beyond 0.25 is a wrong answer"""
     rel = W.grad_rel_err(G, Go)[ok]
     assert np.median(rel) < 1e-9, (what, np.median(rel))
-    assert (rel >= GRAD_TOL).sum() <= max(1, int(0.002 * rel.size)), (what, np.sort(rel)[-5:])     # (one knot in a small batch)
+    nout = int((rel >= GRAD_TOL).sum())
+    assert nout <= max(1, int(0.002 * rel.size)), (what, np.sort(rel)[-5:])     # (one knot in a small batch)
+    assert rel.max() < 0.25, (what, rel.max())
+    if nout:
+        print("assert_grad_close(%s): %d of %d knots beyond 1e-4 (max %.2e)" % (what, nout, rel.size, rel.max()))
 
 
 EXACT_TOL = 1e-8
 
 
-def exact_gradient_errors(oracle, im, name, X, U, Gd):
+def exact_gradient_errors(oracle, im, name, X, U, Gd, Zd=None):
     """Gd: (nq, 2nq+nu, B) = the device's dq3/d(q1,q2,u1) of the LAST step_grad call on `im` for (X, U).
     -> dict of per-knot relative errors (scale = max |exact gradient| of the knot):
        dev = |device - exact at the device's iterate|, orc = |oracle - exact at the oracle's iterate|,
        cross = |device - oracle|, explained = |exact at device's iterate - exact at oracle's iterate|, cond"""
     B = X.shape[1]
     sim = make_sim(oracle, name)
-    Zd = im.grad_iterates(B).cpu().numpy()
+    if Zd is None:
+        Zd = im.grad_iterates(B).cpu().numpy()
     Zo, Go, _ = oracle.grad_iterates(sim, X, U)
     Ed, cd = oracle.arbiter_dq3(sim, X, U, Zd)
     Eo, co = oracle.arbiter_dq3(sim, X, U, Zo)
@@ -64,11 +71,12 @@ def exact_gradient_errors(oracle, im, name, X, U, Gd):
                 iterate_diff=np.abs(Zd - Zo)[:-1].max(0))
 
 
-def assert_grad_exact(oracle, im, name, X, U, DX, DU, ok, what):
+def assert_grad_exact(oracle, im, name, X, U, DX, DU, ok, what, Gd=None, Zd=None):
     """the 1e-4 bar on 100 % of the converged knots, arbitrated in binary128"""
     nq = X.shape[0] // 2
-    Gd = np.concatenate([DX[nq:], DU[nq:]], 1)
-    e = exact_gradient_errors(oracle, im, name, X, U, Gd)
+    if Gd is None:
+        Gd = np.concatenate([DX[nq:], DU[nq:]], 1)
+    e = exact_gradient_errors(oracle, im, name, X, U, Gd, Zd)
     fin = ok & np.isfinite(e["dev"]) & np.isfinite(e["explained"])       # an exactly singular rz has no gradient at all
     assert fin.sum() >= ok.sum() - max(1, ok.sum() // 5000), (what, ok.sum() - fin.sum())
     assert e["dev"][fin].max() < EXACT_TOL, (what, "device vs exact at its own iterate", e["dev"][fin].max())
@@ -95,7 +103,10 @@ def comparable_states(oracle, name, X, U, D, Do, ok):
         Dp = oracle.step_grad_batch(sim, Xp, Up)[0]
         if np.ptp(Dp, axis=1).max() / max(1e-2, np.abs(Do[:, i]).max()) > 10 * STATE_TOL:
             keep[i] = False
-    assert (ok & ~keep).sum() <= max(2, ok.size // 2000)
+    # (soak: two such knots in 1.2 million, profiles/r2_parity_soak.json)
+    assert (ok & ~keep).sum() <= max(1, ok.size // 100000), ("knots excluded as path dependent", int((ok & ~keep).sum()))
+    if (ok & ~keep).any():
+        print("comparable_states(%s): %d of %d converged knots excluded (the oracle does not reproduce itself there)" % (name, int((ok & ~keep).sum()), int(ok.sum())))
     return keep
 
 
@@ -171,6 +182,7 @@ def check_rollout(oracle, lib, device, B, T, name="hopper", u_sigma=0.3):
     x1, U = W.hopper_rollout_inputs(B, T, seed=21, u_sigma=u_sigma)
     im = make_im(name, lib, device)
     X, A, Bm, st, it, _ = im.rollout(torch.tensor(x1), torch.tensor(U))
+    Zd = im.grad_iterates(T * B).cpu().numpy()          # (the hand-over of THIS call: a later gradient pass overwrites it)
     Xn, An, Bn, stn = [t.cpu().numpy() for t in (X, A, Bm, st)]
     Xo, Ao, Bo, bad = oracle.rollout(make_sim(oracle, name), x1, U)
     assert np.all(Xn[:, 0] == x1)
@@ -195,6 +207,15 @@ def check_rollout(oracle, lib, device, B, T, name="hopper", u_sigma=0.3):
     G = np.concatenate([An[:, :, 0], Bn[:, :, 0]], 1)
     Go = np.concatenate([Ao[:, :, 0], Bo[:, :, 0]], 1)
     assert_grad_close(G, Go, ok, "rollout knot 0")
+    # EVERY knot of the rollout through the binary128 arbiter, at the iterate the rollout's gradient pass differentiated at
+    # (the hand-over workspace holds all T*B of them, knot k = t*B + b): the device's states are the inputs
+    n, nu = Xn.shape[0], U.shape[0]
+    Xk = np.ascontiguousarray(Xn[:, :T].reshape(n, T * B))
+    Uk = np.ascontiguousarray(np.asarray(U).reshape(nu, T * B))
+    nq = n // 2
+    Gk = np.concatenate([An[nq:].reshape(nq, n, T * B), Bn[nq:].reshape(nq, nu, T * B)], 1)
+    okk_all = ((stn & 3) == 3).reshape(T * B)
+    assert_grad_exact(oracle, im, name, Xk, Uk, None, None, okk_all, "rollout knots", Gd=Gk, Zd=Zd)
 
 
 def check_bundle(oracle, lib, device, name, B, N):

@@ -126,6 +126,16 @@ EDGE_OPTIONS = [
 ]
 
 
+# lowest agreement rate (status and both iteration counts equal, 96 knots) over 20 seeds x every cooperative model / form on the
+# MI355X (tools/edge_rates.py -> profiles/r3_edge_option_agreement.json); every option not listed: 1.0 on every seed
+MEASURED_MIN_AGREEMENT = {"r_tol=1e-13": 0.948, "eps_min=0": 0.927}
+
+
+def min_agreement(kw):
+    key = ",".join("%s=%g" % kv for kv in kw.items())
+    return MEASURED_MIN_AGREEMENT[key] - 0.03 if key in MEASURED_MIN_AGREEMENT else 0.98
+
+
 def _edge_check(lib, device, name, kw):
     """cooperative against lane-per-problem kernels under unusual solver options: same status and iteration counts,
     states equal to rounding -- including the solves that stop at max_iter or take no iteration at all"""
@@ -141,7 +151,7 @@ def _edge_check(lib, device, name, kw):
     same = (ref[3] == got[3]) & (ref[4] == got[4]).all(0)
     # (a residual tolerance at rounding level: the two association orders reach it an iteration apart on some knots)
     noise_level = kw.get("r_tol", 1) < 1e-10 or kw.get("eps_min", 1) == 0.0      # (or tau = 1: the acceptance test compares noise)
-    assert same.mean() >= (0.8 if noise_level else 0.97), (kw, same.mean())
+    assert same.mean() >= min_agreement(kw), (kw, same.mean())
     fin = np.isfinite(ref[0]).all(0) & np.isfinite(got[0]).all(0)
     # (iterating past the attainable precision ends some solves on a singular factor: non-finite in both kernels alike)
     assert (fin | ~same).all() or fin.mean() > (0.8 if noise_level else 0.95)

@@ -100,16 +100,19 @@ def test_coop3_rollout_emulated(oracle, emu_lib):
     _rollout(oracle, emu_lib, "cpu", 6, 10)
 
 
-EDGE_OPTIONS = [dict(max_iter=0), dict(max_iter=2), dict(max_ls=1), dict(kappa_grad_tol=1e-6), dict(r_tol=1e-3), dict(undercut=5.0), dict(gamma_reg=0.0)]
+EDGE_OPTIONS = [dict(max_iter=0), dict(max_iter=2), dict(max_ls=1), dict(kappa_grad_tol=1e-6), dict(r_tol=1e-3), dict(r_tol=1e-13), dict(eps_min=0.0),
+                dict(undercut=5.0), dict(gamma_reg=0.0)]
 
 
 def _edge(lib, device, kw, name=NAME):
     X, U, ref, got = _pair(lib, device, 64, seed=7, name=name, **kw)
     same = (ref[3] == got[3]) & (ref[4] == got[4]).all(0)
-    assert same.mean() >= 0.95, (kw, same.mean())
+    from test_coop import min_agreement
+    assert same.mean() >= min_agreement(kw), (kw, same.mean())
     fin = np.isfinite(ref[0]).all(0) & np.isfinite(got[0]).all(0)
     e = np.abs(ref[0] - got[0]).max(0)[same & fin]
-    assert np.median(e) < 1e-12 and e.max() < 1e-6, (kw, np.median(e), e.max())
+    noise_level = kw.get("r_tol", 1) < 1e-10 or kw.get("eps_min", 1) == 0.0      # (test_coop.py::_edge_check)
+    assert np.median(e) < 1e-12 and e.max() < (1e-4 if noise_level else 1e-6), (kw, np.median(e), e.max())
 
 
 @pytest.mark.parametrize("kw", EDGE_OPTIONS, ids=lambda d: ",".join("%s=%g" % kv for kv in d.items()))

@@ -37,6 +37,10 @@ def test_comparison_plumbing_selftest(oracle, tmp_path, monkeypatch):
     for name, (h, ke, kg, fric) in W.CONFIGS.items():
         for k in ("D", "DX", "DU"):
             dump("%s_%s" % (name, k), g["%s/%s" % (name, k)])
+        kw = dict(kappa_tol=ke, kappa_grad_tol=kg)
+        if fric:
+            kw["friction"] = fric
+        dump(name + "_ZG", oracle.grad_iterates(oracle.make_sim(name, h, **kw), g[name + "/X"], g[name + "/U"])[0][:-1])
     for k in ("Y", "DX", "DU", "Yp", "DXp", "DUp", "UP"):
         dump("rocket_" + k, g["rocket/" + k])
     B = g["rocket/U"].shape[1]
@@ -67,15 +71,58 @@ def mech_case(name):
     return out
 
 
-def check_mech(c, D, DX, DU, it_eval=None, it_grad=None, ok=None):
+def check_mech(c, D, DX, DU, it_eval=None, it_grad=None, ok=None, arb=None):
+    """states: 1e-6 (north_star) on every knot.  Gradients: 1e-4 on every knot EXCEPT where the map iterate -> gradient is
+    itself ill-conditioned -- measured on this repository's two implementations (profiles/r2_parity_sweep.json): both
+    reproduce the exact gradient at their own iterate to 1e-12, their iterates differ by ~1e-11 (inside r_tol), and on
+    0.05-0.25 % of hopper / planar-push knots the exact gradient moves by up to 7e-2 between them (cond(rz) up to 1e27).
+    The reference will differ from us in the same way, so a knot beyond 1e-4 is accepted only if the binary128 arbiter
+    (oracle/arbiter.c) says so: `arb` = dict(own = exact gradient at OUR iterate (nq, 2nq+nu, B), cond = exact condition
+    numbers, ref = exact gradient at the REFERENCE's iterate when <model>_ZG.bin was exported, else None):
+      * with the reference iterate: |ours - reference| <= 1e-4 + 2 |exact(ours) - exact(reference)| on every knot;
+      * without it: beyond 1e-4 only where cond(rz) > 1e10, on at most 0.5 % of the knots."""
     assert np.abs(D - c["D"]).max() <= 1e-6 * max(1.0, np.abs(c["D"]).max())          # north_star: 1e-6 on states
-    assert W.grad_rel_err(DX, c["DX"]).max() <= 1e-4 and W.grad_rel_err(DU, c["DU"]).max() <= 1e-4
+    G = np.concatenate([DX, DU], 1)
+    Gr = np.concatenate([c["DX"], c["DU"]], 1)
+    rel = W.grad_rel_err(G, Gr)
+    bad = rel > 1e-4
+    if bad.any():
+        assert arb is not None, ("gradients beyond 1e-4 and no arbiter data", rel.max())
+        nq = D.shape[0] // 2
+        Bn = D.shape[1]
+        sc = np.maximum(np.abs(Gr[nq:]).reshape(-1, Bn).max(0), 1e-12)
+        own_err = np.abs(G[nq:] - arb["own"]).reshape(-1, Bn).max(0) / sc
+        assert own_err[np.isfinite(own_err)].max() < 1e-8                              # we are exact at our own iterate
+        if arb.get("ref") is not None:
+            expl = np.abs(arb["own"] - arb["ref"]).reshape(-1, Bn).max(0) / sc
+            assert (rel - 2.0 * expl)[np.isfinite(expl)].max() < 1e-4, (rel - 2.0 * expl).max()
+        else:
+            assert (arb["cond"][bad] > 1e10).all() and bad.mean() <= 0.005, (bad.mean(), arb["cond"][bad].min())
     if c["IT"] is not None and (c["IT"] >= 0).all() and it_eval is not None:
         # the fused loop serves f (row 0) and fx = fu (rows 1, 2) of the reference: same iteration counts
         assert np.array_equal(it_eval, c["IT"][0].astype(int)) and np.array_equal(it_grad, c["IT"][1].astype(int))
         assert np.array_equal(c["IT"][1], c["IT"][2])
     if c["ST"] is not None and (c["ST"] >= 0).all() and ok is not None:
         assert np.array_equal(ok.astype(int), (c["ST"][:2] == 1).all(0).astype(int))
+
+
+def arbiter_data(oracle, name, c, Zown):
+    """exact (binary128) gradients at our iterate Zown ((nz+1) x B, clamp in the last row) and, if exported, at the reference's"""
+    h, ke, kg, fric = W.CONFIGS[name]
+    kw = dict(kappa_tol=ke, kappa_grad_tol=kg)
+    if fric:
+        kw["friction"] = fric
+    sim = oracle.make_sim(name, h, **kw)
+    own, cond = oracle.arbiter_dq3(sim, c["X"], c["U"], Zown)
+    refg = None
+    p = os.path.join(REF, name + "_ZG.bin")
+    if os.path.exists(p):
+        nz = Zown.shape[0] - 1
+        Zr = ref(name + "_ZG", (nz, c["X"].shape[1]))
+        if np.isfinite(Zr).all():
+            # the reference differentiates with its own clamp max(reg_val, kappa_grad gamma_reg): ours is the same rule
+            refg, _ = oracle.arbiter_dq3(sim, c["X"], c["U"], np.vstack([Zr, Zown[-1:]]))
+    return dict(own=own, cond=cond, ref=refg)
 
 
 @have_ref
@@ -90,8 +137,10 @@ def _oracle_mech(oracle, name):
     kw = dict(kappa_tol=ke, kappa_grad_tol=kg)
     if fric:
         kw["friction"] = fric
-    Do, DXo, DUo, bad = oracle.step_grad_batch(oracle.make_sim(name, h, **kw), c["X"], c["U"])
-    check_mech(c, Do, DXo, DUo)
+    sim = oracle.make_sim(name, h, **kw)
+    Do, DXo, DUo, bad = oracle.step_grad_batch(sim, c["X"], c["U"])
+    Zo, _, _ = oracle.grad_iterates(sim, c["X"], c["U"])
+    check_mech(c, Do, DXo, DUo, arb=arbiter_data(oracle, name, c, Zo))
 
 
 @have_ref
@@ -149,12 +198,13 @@ def _oracle_bundle(oracle, name):
 @have_ref
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(W.CONFIGS))
-def test_device_matches_julia_reference(gpu_lib, name):
+def test_device_matches_julia_reference(oracle, gpu_lib, name):
     import parity_checks as P
     c = mech_case(name)
     im = P.make_im(name, gpu_lib, "cuda:0")
     D, DX, DU, st, it = [t.cpu().numpy() for t in im.step_grad(torch.tensor(c["X"]), torch.tensor(c["U"]))]
-    check_mech(c, D, DX, DU, it[0], it[1], (st & 3) == 3)
+    Zd = im.grad_iterates(c["X"].shape[1]).cpu().numpy()
+    check_mech(c, D, DX, DU, it[0], it[1], (st & 3) == 3, arb=arbiter_data(oracle, name, c, Zd))
     # the reference callback signatures on host vectors (the path a Julia caller takes through the C ABI)
     from optimization_dynamics_amd import dynamics as dyn
     n = c["X"].shape[0]
