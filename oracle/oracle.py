@@ -296,3 +296,32 @@ def rollout(sim, x1, U, grads=True, bufs=None):
     if grads:
         return X, A.reshape(n, n, T, B, order="F"), Bm.reshape(n, nu, T, B, order="F"), bad
     return X, None, None, bad
+
+
+def arbiter_soc_projection(u_max, u, exact_acceptance=True):
+    """the thrust-cone projection (src/models/rocket/dynamics.jl:168-186) by the same interior-point loop in binary128
+    (oracle/arbiter.c); exact_acceptance: the line search accepts its first trial, as it does in exact arithmetic (the equality
+    rows are linear).  -> ok, z (10), iterations, accepted trial per iteration, linearity defect seen"""
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    z = np.zeros(10)
+    it = C.c_int()
+    trials = (C.c_int * 128)()
+    lerr = C.c_double()
+    ok = lib().od_arbiter_soc_projection(C.c_double(u_max), _p(u), int(bool(exact_acceptance)), _p(z), C.byref(it), trials, C.byref(lerr))
+    return ok, z, it.value, list(trials[:it.value]), lerr.value
+
+
+def project_thrust_cone(u, u_max):
+    """closed-form Euclidean projection onto {|u_1:2| <= u_3, 0 <= u_3 <= u_max}: minimise (min(a, t) - a)^2 + (t - u_3)^2 over the
+    height t (a = |u_1:2|): on t <= a the minimiser is (a + u_3)/2, on t >= a it is u_3, each clipped to its interval"""
+    u = np.asarray(u, dtype=np.float64)
+    a, t = float(np.hypot(u[0], u[1])), float(u[2])
+    cands = []
+    t1 = min(max(0.5 * (a + t), 0.0), min(a, u_max))
+    cands.append(((t1 - a) ** 2 + (t1 - t) ** 2, t1, t1))
+    if u_max >= a:
+        t2 = min(max(t, a), u_max)
+        cands.append(((t2 - t) ** 2, a, t2))
+    _, r, tt = min(cands)
+    s = r / a if a > 0 else 0.0
+    return np.array([u[0] * s, u[1] * s, tt])

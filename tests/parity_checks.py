@@ -284,6 +284,35 @@ def check_ls_kat(lib, device):
     assert np.allclose(theta.reshape(2, 3, order="F"), [[1, 1, 0], [0, 1, 1]], atol=1e-10)
 
 
+# The thrust-cone projection runs with eps_min = 0 (tau = 1, src/models/rocket/dynamics.jl:81): from its first full step on
+# the equality residual is rounding noise and the line-search test (r_cand <= r_vio || k_cand <= k_vio) compares noise, so
+# two correct double-precision implementations can accept different step lengths.  Settled with the binary128 arbiter
+# (oracle/arbiter.c::od_arbiter_soc_projection; the equality rows are linear, so exact arithmetic always accepts the
+# first trial): measured on the MI355X over 6000 controls (tools/proj_paths.py -> profiles/r3_projection_paths.json) the
+# device follows the exact path to 1e-7 on 85.4-86.3 % of them and the oracle on 91.6-93.3 %; off the path every end point
+# is within 3.3e-4 of the exact path's (the solver's own kappa_tol = 1e-4 level), and all of them -- exact path included --
+# within 4.3e-3 of the closed-form Euclidean projection (what a kappa_tol-accurate interior point is worth near the apex).
+PROJ_OFF_PATH_RATE = {torch.float64: 0.15, torch.float32: 0.002}       # measured upper rates (fp32: "path" = 2e-3)
+PROJ_PATH_TOL = {torch.float64: 1e-7, torch.float32: 2e-3}
+PROJ_OFF_PATH_DEV = {torch.float64: 5e-4, torch.float32: 6e-3}
+
+
+def projection_paths(oracle, U, UP, dtype=torch.float64):
+    """-> on_path (B,) bool for the device's projected controls UP (3, B) against the exact-arithmetic path; asserts the
+    off-path rule: deviation at kappa_tol level, everything near the closed-form projection, count within rate + 3 sigma"""
+    B = U.shape[1]
+    E = np.stack([oracle.arbiter_soc_projection(12.5, U[:, b], True)[1][:3] for b in range(B)], 1)
+    Pc = np.stack([oracle.project_thrust_cone(U[:, b], 12.5) for b in range(B)], 1)
+    sc = np.maximum(1.0, np.abs(Pc).max(0))
+    dev = np.abs(UP - E).max(0) / sc
+    on = dev < PROJ_PATH_TOL[dtype]
+    assert dev[~on].max(initial=0.0) < PROJ_OFF_PATH_DEV[dtype], dev.max()
+    assert (np.abs(UP - Pc).max(0) / sc).max() < 6e-3 and (np.abs(E - Pc).max(0) / sc).max() < 6e-3
+    r = PROJ_OFF_PATH_RATE[dtype]
+    assert (~on).sum() <= B * r + 3.0 * np.sqrt(B * r * (1 - r)) + 1, ((~on).sum(), B)
+    return on, E
+
+
 def check_rocket(oracle, lib, device, B, dtype=torch.float64):
     X, U = W.rocket_inputs(B, seed=41)
     info = rk.RocketInfo(models.rocket, 12.5, 0.05, dtype=dtype, device=device, lib=lib)
@@ -291,39 +320,33 @@ def check_rocket(oracle, lib, device, B, dtype=torch.float64):
     for project in (False, True):
         Y, DX, DU, UP, st = info.solve(torch.tensor(X), torch.tensor(U), project=project, grads=True)
         Y, DX, DU, st = Y.double().cpu().numpy(), DX.double().cpu().numpy(), DU.double().cpu().numpy(), st.cpu().numpy()
-        ntight = nfail = 0
         nb = min(B, 24)
-        for b in range(nb):
-            tS, tG = tolS, tolG
-            if project:
-                ok, y, dx, du = oracle.rocket_proj(0.05, 12.5, X[:, b], U[:, b])
-                up = oracle.soc_projection(12.5, U[:, b], False)[1][:3]
-                eu = np.abs(UP[:, b].double().cpu().numpy() - up).max() / max(1, np.abs(up).max())
-                if (st[b] & 0x33) != 0x33:
-                    # a projection that runs out of iterations is a reported status, not an error (the reference warns
-                    # and copies the result out, src/models/rocket/dynamics.jl:178-186): ~0.02 % of solves on these inputs
-                    nfail += 1
-                    continue
-                # The projection runs with eps_min = 0 (tau = 1): its equality residual sits at rounding
-                # level from the 2nd iteration on, so the reference's line-search test
-                # (r_cand <= r_vio || k_cand <= k_vio) compares rounding noise and two implementations
-                # can accept different step lengths.  Both then end on kappa_tol-accurate points
-                # (kappa_tol = 1e-4, dynamics.jl:79).  Same path -> tight bound; else kappa_tol-level.
-                if eu < (1e-7 if dtype == torch.float64 else 2e-3):
-                    ntight += 1
-                else:
-                    assert eu < (1e-3 if dtype == torch.float64 else 2e-2)        # both are kappa_tol = 1e-4 accurate
-                    tS, tG = 1e-3, 5e-2
-            else:
+        if project:
+            UPn = UP.double().cpu().numpy()
+            conv = (st[:nb] & 0x33) == 0x33
+            # a projection that runs out of iterations is a reported status, not an error (the reference warns and copies
+            # the result out, src/models/rocket/dynamics.jl:178-186): ~0.02 % of solves on these inputs
+            assert (~conv).sum() <= 1
+            idx = np.nonzero(conv)[0]
+            on, E = projection_paths(oracle, U[:, idx], UPn[:, idx], dtype)
+            for k, b in enumerate(idx):
+                # the dynamics step and its gradients at the control the DEVICE projected to: no path dependence left
+                ok, y, dz, it = oracle.rocket(0.05, X[:, b], UPn[:, b], True)
+                assert np.abs(Y[:, b] - y).max() < tolS * max(1, np.abs(y).max())
+                assert np.abs(DX[:, :, b] - dz[:, :12]).max() < tolG * max(1, np.abs(dz[:, :12]).max())
+                # fu = dz_dyn[:, u] * d(projection)/du (:264-267); the projection's own gradient is compared where the oracle's
+                # projection is on the same (exact) path, at kappa_tol level otherwise
+                s_, zo, dzp, ito = oracle.soc_projection(12.5, U[:, b], True)
+                du = dz[:, 12:15] @ dzp[:3, :3]
+                same = on[k] and np.abs(zo[:3] - E[:, k]).max() < PROJ_PATH_TOL[dtype] * max(1.0, np.abs(E[:, k]).max())
+                assert np.abs(DU[:, :, b] - du).max() < (tolG if same else 5e-2) * max(1, np.abs(du).max())
+        else:
+            for b in range(nb):
                 ok, y, dz, it = oracle.rocket(0.05, X[:, b], U[:, b], True)
-                dx, du = dz[:, :12], dz[:, 12:15]
                 assert (st[b] & 3) == 3
-                ntight += 1
-            assert np.abs(Y[:, b] - y).max() < tS * max(1, np.abs(y).max())
-            assert np.abs(DX[:, :, b] - dx).max() < tG * max(1, np.abs(dx).max())
-            assert np.abs(DU[:, :, b] - du).max() < tG * max(1, np.abs(du).max())
-        # (how many solves share the oracle's path is a property of the draw, 55-85 %; every other one met the kappa_tol-level bars above)
-        assert ntight >= 0.4 * nb and nfail <= 1, (ntight, nfail, nb)
+                assert np.abs(Y[:, b] - y).max() < tolS * max(1, np.abs(y).max())
+                assert np.abs(DX[:, :, b] - dz[:, :12]).max() < tolG * max(1, np.abs(dz[:, :12]).max())
+                assert np.abs(DU[:, :, b] - dz[:, 12:15]).max() < tolG * max(1, np.abs(dz[:, 12:15]).max())
     if dtype == torch.float64:
         d = np.zeros(12); dxs = np.zeros((12, 12)); dus = np.zeros((12, 3))
         rk.f_rocket_proj(d, info, X[:, 0], U[:, 0], None)
@@ -380,18 +403,11 @@ def check_soc_projection(oracle, lib, device, B=96):
     assert np.abs(UP[:, 0] - U[:, 0]).max() < 2e-3 and np.abs(DP[:, :, 0] - np.eye(3)).max() < 2e-2
     assert abs(UP[2, 1] - 12.5) < 2e-3 and np.abs(UP[:2, 1]).max() < 1e-3
     assert np.abs(UP[:, 2]).max() < 5e-2
-    ntight = 0
-    for b in range(B):
+    on, E = projection_paths(oracle, U, UP)
+    for b in np.nonzero(on)[0]:
         s, z, dz, it = oracle.soc_projection(12.5, U[:, b], True)
-        eu = np.abs(UP[:, b] - z[:3]).max() / max(1.0, np.abs(z[:3]).max())
-        # eps_min = 0 makes the accepted step lengths a matter of rounding noise (see check_rocket):
-        # same path -> tight, otherwise both are kappa_tol-accurate solutions
-        if eu < 1e-7:
-            ntight += 1
+        if np.abs(z[:3] - E[:, b]).max() < 1e-7 * max(1.0, np.abs(E[:, b]).max()):       # the oracle on the exact path as well
             assert np.abs(DP[:, :, b] - dz[:3, :3]).max() < GRAD_TOL * max(1.0, np.abs(dz[:3, :3]).max())
-        else:
-            assert eu < 2e-4
-    assert ntight >= 0.7 * B
     # scalar mirrors of the reference functions
     up0 = rk.soc_projection(U[:, 5], info)
     dp0 = rk.soc_projection_gradient(U[:, 5], info)
