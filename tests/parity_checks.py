@@ -627,24 +627,35 @@ def check_coop_rollout(oracle, lib, device, B, T):
     assert (it1 == it).double().mean().item() > 0.995       # a differing count needs a knot at the edge of a tolerance
 
 
-def check_coop_policy_rollout(lib, device, B=6, T=12, na=3):
-    """closed-loop rollouts (iLQR forward pass, od_rollout_policy) through the cooperative kernel against the
-    lane-per-problem one: same controls applied, same states to rounding"""
+def planar_push_rollout_inputs(B, T, seed=5):
+    rng = np.random.default_rng(seed + W.SEED_OFFSET)
+    q0 = np.array([0.0, 0.0, 0.0, -0.1 - 1e-8, -0.01])[:, None] + np.r_[np.zeros((4, B)), rng.normal(0, 0.02, (1, B))]
+    U = np.zeros((2, T, B)); U[0, : T // 2] = rng.uniform(0.3, 0.6, (T // 2, B)); U[1] = rng.normal(0, 0.1, (T, B))
+    return np.vstack([q0, q0]), U
+
+
+def check_coop_policy_rollout(lib, device, B=6, T=12, na=3, name="hopper", mode=2):
+    """closed-loop rollouts (iLQR forward pass, od_rollout_policy) through a cooperative kernel (mode 2: 16 lanes per problem,
+    3: 8 lanes) against the lane-per-problem one: same controls applied, same states to rounding"""
     from optimization_dynamics_amd.dynamics import _ptr
-    x1, U = W.hopper_rollout_inputs(B, T, seed=4, u_sigma=0.3)
-    im = make_im("hopper", lib, device)
+    if name == "hopper":
+        x1, U = W.hopper_rollout_inputs(B, T, seed=4, u_sigma=0.3)
+    else:
+        x1, U = planar_push_rollout_inputs(B, T)
+    im = make_im(name, lib, device)
     dev = im.device
     x1d, Ud = torch.tensor(x1, device=dev), torch.tensor(U, device=dev)
     im.set_cooperative(1)
     X = im.rollout(x1d, Ud, grads=False)[0]
-    n, m = 8, 2
+    n, m = x1.shape[0], U.shape[0]
     rng = np.random.default_rng(2)
     K = torch.tensor(0.05 * rng.normal(size=(m * n, T, B)), device=dev)
     k = torch.tensor(0.1 * rng.normal(size=(m, T, B)), device=dev)
     alphas = torch.tensor([1.0, 0.5, 0.0], dtype=torch.float64, device=dev)
     out = {}
-    for mode in (1, 2):
-        im.set_cooperative(mode)
+    for md in (1, mode):
+        im.set_cooperative(md)
+        assert bool(lib.cdll.od_uses_cooperative(im._h, na * B)) == (md != 1)
         im._use_current_stream()
         Xc = torch.empty(n, T + 1, na * B, dtype=torch.float64, device=dev)
         Uc = torch.empty(m, T, na * B, dtype=torch.float64, device=dev)
@@ -652,11 +663,11 @@ def check_coop_policy_rollout(lib, device, B=6, T=12, na=3):
         lib.check(lib.cdll.od_rollout_policy(im._h, B, T, na, _ptr(alphas), _ptr(x1d.contiguous()), _ptr(X.contiguous()),
                                              _ptr(Ud.contiguous()), _ptr(K), _ptr(k), _ptr(Xc), _ptr(Uc), _ptr(st), 0))
         im.synchronize()
-        out[mode] = (Xc.cpu().numpy(), Uc.cpu().numpy(), st.cpu().numpy())
-    assert np.array_equal(out[1][2], out[2][2])
-    assert np.abs(out[1][0] - out[2][0]).max() < 1e-7 and np.abs(out[1][1] - out[2][1]).max() < 1e-7
+        out[md] = (Xc.cpu().numpy(), Uc.cpu().numpy(), st.cpu().numpy())
+    assert np.array_equal(out[1][2], out[mode][2])
+    assert np.abs(out[1][0] - out[mode][0]).max() < 1e-7 and np.abs(out[1][1] - out[mode][1]).max() < 1e-7
     # alpha = 0 with x = xbar reproduces the nominal trajectory (the feedback term vanishes)
-    assert np.abs(out[2][0][:, :, 2 * B:] - X.cpu().numpy()).max() < 1e-7
+    assert np.abs(out[mode][0][:, :, 2 * B:] - X.cpu().numpy()).max() < 1e-7
 
 
 def check_rollout_finite_undercut(oracle, lib, device, B=6, T=8):

@@ -74,10 +74,7 @@ def test_coop3_bundle_emulated(oracle, emu_lib):
 
 
 def _rollout(oracle, lib, device, B, T):
-    rng = np.random.default_rng(5 + W.SEED_OFFSET)
-    q0 = np.array([0.0, 0.0, 0.0, -0.1 - 1e-8, -0.01])[:, None] + np.r_[np.zeros((4, B)), rng.normal(0, 0.02, (1, B))]
-    x1 = np.vstack([q0, q0])
-    U = np.zeros((2, T, B)); U[0, : T // 2] = rng.uniform(0.3, 0.6, (T // 2, B))      # (harder pushes leave knots at max_iter, in the oracle too); U[1] = rng.normal(0, 0.1, (T, B))
+    x1, U = P.planar_push_rollout_inputs(B, T)          # (harder pushes leave knots at max_iter, in the oracle too)
     im = P.make_im(NAME, lib, device)
     im.set_cooperative(2)
     x1d, Ud = torch.tensor(x1, device=device), torch.tensor(U, device=device)
@@ -156,3 +153,45 @@ def test_coop3_rollout(oracle, gpu_lib):
 def test_coop3_edge_options(gpu_lib, kw):
     _edge(gpu_lib, "cuda:0", kw)
     _edge(gpu_lib, "cuda:0", kw, "hopper")
+
+
+# ---- every other kernel of the 8-lane form, and the lane-per-problem kernels it replaced by default -------------------------
+def _bundle_forms(lib, device, name, B, N, modes):
+    """gradient bundle through two kernel forms: same fit to the amplified rounding of the samples (1e-8 / eps)"""
+    from optimization_dynamics_amd import gradient_bundle as gbm, models
+    X, U = W.knots(name, B, seed=33)
+    gb = gbm.GradientBundle(models.BY_NAME[name], N=N, eps=1e-4, seed=5)
+    out = []
+    for mode in modes:
+        im = P.make_im(name, lib, device, info=gb)
+        im.set_cooperative(mode)
+        dz, st = gbm.gradient_batch(im, gb, torch.tensor(X, device=device), torch.tensor(U, device=device))
+        out.append((dz.cpu().numpy(), st.cpu().numpy()))
+    ok = (out[0][1] == 1) & (out[1][1] == 1)
+    assert ok.mean() > 0.9
+    d = np.abs(out[0][0] - out[1][0])[:, :, ok].max() / max(1.0, np.abs(out[0][0][:, :, ok]).max())
+    assert d < 1e-3, d
+
+
+def test_bundle_kernel_forms_emulated(emu_lib):
+    _bundle_forms(emu_lib, "cpu", NAME, 3, 64, (1, 3))
+    _bundle_forms(emu_lib, "cpu", "hopper", 3, 64, (1, 3))
+
+
+def test_policy_rollout_eight_lane_form_emulated(emu_lib):
+    P.check_coop_policy_rollout(emu_lib, "cpu", B=4, T=8, name=NAME, mode=3)
+    P.check_coop_policy_rollout(emu_lib, "cpu", B=4, T=8, name="hopper", mode=3)
+
+
+@pytest.mark.gpu
+def test_bundle_kernel_forms(gpu_lib):
+    """k_bundle_coop3<planar push> against k_bundle_ldsf (the LDS factor store, lane per problem); k_bundle_coop3<hopper> (what
+    4097..8192 hopper samples run: 50 knots x 101) against k_bundle"""
+    _bundle_forms(gpu_lib, "cuda:0", NAME, 50, 256, (1, 0))
+    _bundle_forms(gpu_lib, "cuda:0", "hopper", 50, 100, (1, 0))
+
+
+@pytest.mark.gpu
+def test_policy_rollout_eight_lane_form(gpu_lib):
+    P.check_coop_policy_rollout(gpu_lib, "cuda:0", B=16, T=20, name=NAME, mode=3)
+    P.check_coop_policy_rollout(gpu_lib, "cuda:0", B=16, T=20, name="hopper", mode=3)
