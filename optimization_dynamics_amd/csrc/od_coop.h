@@ -652,8 +652,12 @@ OD_HD typename RO::B coop_trials_lanes(const CoopLanes<CM, RO>& L, const double*
 // ---------------------------------------------------------------------------------------------------------------
 // one predictor-corrector iteration (od_solver.h::ip_iteration), line search included
 // ---------------------------------------------------------------------------------------------------------------
+// Returns true if the iteration left EVERYTHING it reads unchanged -- a zero step length (a cone variable exactly on its
+// boundary) whose first trial reproduced both violations bit for bit: every further iteration would then repeat this one, so
+// the caller may go straight to max_iter (same iterate, status and iteration counts; 9 of the 29 knots of the headline
+// workload that jam do this, from their 34th iteration on average: profiles/r3_jam_knots.txt).
 template <class CM, class RO>
-OD_HD void coop_iteration(const CoopLanes<CM, RO>& L, const Opts<double>& o, const double* th, const double* pre, double* tr,
+OD_HD bool coop_iteration(const CoopLanes<CM, RO>& L, const Opts<double>& o, const double* th, const double* pre, double* tr,
                           CoopVec<CM::NQ, typename RO::V>& z, CoopRes<CM::NQ, typename RO::V>& r, double& r_vio, double& k_vio,
                           double& reg_prev, int& status, CoopFact<CM, RO>& f) {
   using V = typename RO::V;
@@ -720,10 +724,12 @@ OD_HD void coop_iteration(const CoopLanes<CM, RO>& L, const Opts<double>& o, con
     }
     trial(alpha);                                                        // the row lands on the chosen trial
   }
+  const bool fixed_point = (alpha == 0.0) && done && ls == 0 && r_c == r_vio && k_c == k_vio;
   z = zc;
   r = rc;
   r_vio = r_c;
   k_vio = k_c;
+  return fixed_point;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -783,7 +789,7 @@ OD_HD int coop_ip_step(const CoopLanes<CM, RO>& L, const Opts<double>& o, const 
       if (!last) status |= OD_ST_EVAL_OK;
     }
     if (eval_done && grad_done) break;
-    coop_iteration<CM, RO>(L, o, th, pre, tr, z, r, r_vio, k_vio, reg_prev, status, f);
+    if (coop_iteration<CM, RO>(L, o, th, pre, tr, z, r, r_vio, k_vio, reg_prev, status, f) && it + 1 < o.max_iter) it = o.max_iter - 1;
   }
 #pragma unroll
   for (int k = 0; k < NQ; ++k) z.q[k] = qs[k];

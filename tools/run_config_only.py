@@ -1,0 +1,26 @@
+"""one BASELINE config alone, a few calls (target of rocprofv3 / PMC runs): python tools/run_config_only.py bundle|acrobot|pp_step [reps]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import workloads as W, parity_checks as P
+import optimization_dynamics_amd as od
+lib = od.default_library(); dev = "cuda:0"
+what = sys.argv[1]; reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+if what == "bundle":
+    im = P.make_im("planar_push", lib, dev)
+    gb = od.GradientBundle(od.planarpush, N=256, eps=1e-4, seed=0)
+    X, U = W.knots("planar_push", 50, seed=2)
+    fn = lambda: od.gradient_batch(im, gb, Xd, Ud)
+elif what == "acrobot":
+    im = P.make_im("acrobot_impact", lib, dev)
+    X, U = W.knots("acrobot_impact", 1024, seed=1)
+    fn = lambda: im.step_grad(Xd, Ud)
+elif what == "pp_step":
+    im = P.make_im("planar_push", lib, dev)
+    X, U = W.knots("planar_push", 65536, seed=1)
+    fn = lambda: im.step_grad(Xd, Ud)
+Xd, Ud = torch.tensor(X, device=dev), torch.tensor(U, device=dev)
+for _ in range(reps):
+    fn()
+torch.cuda.synchronize()
