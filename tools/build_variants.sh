@@ -1,0 +1,9 @@
+# Measurement-only variant builds (never shipped): bash tools/build_variants.sh
+# fused-gradient cost probe: the hopper TU with -DOD_EXPERIMENT_FUSED_GRAD_COST linked against the other objects
+set -e
+cd "$(dirname "$0")/../optimization_dynamics_amd/csrc"
+make -j8 > /dev/null
+mkdir -p ../../variants/build_fg
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -DOD_EXPERIMENT_FUSED_GRAD_COST -c od_model_hopper.hip -o ../../variants/build_fg/od_model_hopper.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../variants/libod_fusedgradcost.so $(ls build/*.o | grep -v od_model_hopper) ../../variants/build_fg/od_model_hopper.o
+echo "variants/libod_fusedgradcost.so: python tools/time_rollout.py variants/libod_fusedgradcost.so 0 4096 100"
