@@ -7,3 +7,8 @@ mkdir -p ../../variants/build_fg
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -DOD_EXPERIMENT_FUSED_GRAD_COST -c od_model_hopper.hip -o ../../variants/build_fg/od_model_hopper.o
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../variants/libod_fusedgradcost.so $(ls build/*.o | grep -v od_model_hopper) ../../variants/build_fg/od_model_hopper.o
 echo "variants/libod_fusedgradcost.so: python tools/time_rollout.py variants/libod_fusedgradcost.so 0 4096 100"
+# row-decoupling probe: per-row progress in the 16-lane cooperative rollout
+mkdir -p ../../variants/build_rd
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -DOD_EXPERIMENT_ROW_DECOUPLING -c od_model_hopper.hip -o ../../variants/build_rd/od_model_hopper.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../variants/libod_rowdecoupled.so $(ls build/*.o | grep -v od_model_hopper) ../../variants/build_rd/od_model_hopper.o
+echo "variants/libod_rowdecoupled.so: python tools/time_rollout.py variants/libod_rowdecoupled.so 0 4096 100"

@@ -6,7 +6,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import bench, workloads as W, parity_checks as P
 import optimization_dynamics_amd as od
-lib = od.default_library(); dev = "cuda:0"
+from optimization_dynamics_amd import _lib
+lib = _lib.Library(sys.argv[2]) if len(sys.argv) > 2 else od.default_library()      # (a variant build: tools/build_variants.sh)
+dev = "cuda:0"
 def h(*ts):
     m = hashlib.sha256()
     for t in ts:
