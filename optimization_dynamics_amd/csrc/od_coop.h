@@ -659,7 +659,7 @@ OD_HD typename RO::B coop_trials_lanes(const CoopLanes<CM, RO>& L, const double*
 template <class CM, class RO>
 OD_HD bool coop_iteration(const CoopLanes<CM, RO>& L, const Opts<double>& o, const double* th, const double* pre, double* tr,
                           CoopVec<CM::NQ, typename RO::V>& z, CoopRes<CM::NQ, typename RO::V>& r, double& r_vio, double& k_vio,
-                          double& reg_prev, int& status, CoopFact<CM, RO>& f) {
+                          double& reg_prev, int& status, CoopFact<CM, RO>& f, int& ls_hint) {
   using V = typename RO::V;
   using Vec = CoopVec<CM::NQ, V>;
   using Res = CoopRes<CM::NQ, V>;
@@ -700,7 +700,9 @@ OD_HD bool coop_iteration(const CoopLanes<CM, RO>& L, const Opts<double>& o, con
     coop_viol<CM, RO>(L, rc, r_c, k_c);
     return r_c <= r_vio || k_c <= k_vio;
   };
-  const int nseq = o.max_ls < 2 ? o.max_ls : 2;
+  // (a knot whose previous iteration needed more than two trials -- a jam -- goes to the lane-parallel round at once: the
+  // accepted trial is the same either way)
+  const int nseq = ls_hint >= 2 ? 0 : (o.max_ls < 2 ? o.max_ls : 2);
   bool done = false;
   int ls = 0;
   for (; ls < nseq; ++ls) {
@@ -716,7 +718,9 @@ OD_HD bool coop_iteration(const CoopLanes<CM, RO>& L, const Opts<double>& o, con
       if (m != 0) {
         alpha = od_ldexp(alpha, -__builtin_ctz(m));                      // first accepted trial of the round
         found = true;
+        ls = j0 + __builtin_ctz(m);
       } else {
+        ls = o.max_ls - 1;
         const int left = o.max_ls - 1 - j0;                              // trials after j0: move on by 16, or to the last
         alpha = od_ldexp(alpha, -(left < 16 ? left : 16));
         if (left < 16) break;                                            // alpha is now the last trial's step
@@ -725,6 +729,7 @@ OD_HD bool coop_iteration(const CoopLanes<CM, RO>& L, const Opts<double>& o, con
     trial(alpha);                                                        // the row lands on the chosen trial
   }
   const bool fixed_point = (alpha == 0.0) && done && ls == 0 && r_c == r_vio && k_c == k_vio;
+  ls_hint = ls;                                                          // index of the accepted trial
   z = zc;
   r = rc;
   r_vio = r_c;
@@ -752,6 +757,7 @@ OD_HD int coop_ip_step(const CoopLanes<CM, RO>& L, const Opts<double>& o, const 
   bool eval_done = false, grad_done = !want_grad;
   int status = OD_ST_FACTOR_OK;
   double reg_prev = 0.0;
+  int ls_hint = 0;
   iters[0] = iters[1] = 0;
   for (int it = 0;; ++it) {
     const bool req = r_vio < o.r_tol;
@@ -789,7 +795,7 @@ OD_HD int coop_ip_step(const CoopLanes<CM, RO>& L, const Opts<double>& o, const 
       if (!last) status |= OD_ST_EVAL_OK;
     }
     if (eval_done && grad_done) break;
-    if (coop_iteration<CM, RO>(L, o, th, pre, tr, z, r, r_vio, k_vio, reg_prev, status, f) && it + 1 < o.max_iter) it = o.max_iter - 1;
+    if (coop_iteration<CM, RO>(L, o, th, pre, tr, z, r, r_vio, k_vio, reg_prev, status, f, ls_hint) && it + 1 < o.max_iter) it = o.max_iter - 1;
   }
 #pragma unroll
   for (int k = 0; k < NQ; ++k) z.q[k] = qs[k];
