@@ -365,6 +365,24 @@ def main():
         aux = dict(workload="od_step_grad, hopper, %d independent knots" % Bk, units_per_s=Bk / tk, ms=tk * 1e3,
                    mean_iterations=float(itk[0].double().mean().item()))
 
+    aux_roll = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not emu:
+        # auxiliary, NOT the headline: the same rollout step at a batch that fills the chip (65 536 trajectories x T knots, 64
+        # per wavefront) -- where the roofline fraction of this path stands when the batch is not the limit
+        Br = 65536
+        xr, Ur = workload_slice(0, Br, Br, T)
+        xrd, Urd = torch.tensor(xr, device=dev), torch.tensor(Ur, device=dev)
+        orr = None
+        orr = im.rollout_compact(xrd, Urd, out=orr)[-1]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ts = []
+        for _ in range(3):
+            e0.record(stream); r_ = im.rollout_compact(xrd, Urd, out=orr); orr = r_[-1]; e1.record(stream); sync()
+            ts.append(e0.elapsed_time(e1))
+        aux_roll = dict(workload="od_rollout_compact, hopper, %d rollouts x T=%d" % (Br, T), ms=float(np.median(ts)), units_per_s=Br * T / (np.median(ts) * 1e-3),
+                        mean_iterations=float(r_[3][0].double().mean().item()))
+        del orr, r_, xrd, Urd
+
     if rank == 0:
         stats = json.load(open(os.path.join(ROOT, "optimization_dynamics_amd", "csrc", "gen", "stats.json")))["hopper"]
         F, per_iter, grad = algorithmic_flops_per_unit(it_eval, stats)
@@ -400,14 +418,19 @@ def main():
                          "latency_floor_ms": latency_floor_ms,
                          "why_not_0.40": "one trajectory is T=100 sequential knots x ~8.2 interior-point iterations x ~870 dependent instructions: %s ms "
                                          "for ANY batch (latency_floor_ms); at batch 4096 every SIMD holds one wavefront of four trajectories, so the step "
-                                         "cannot be shorter than that and frac <= %.2f; the fp64 roof is approached only by independent knots "
-                                         "(aux_independent_knots)" % ("%.2f" % latency_floor_ms if latency_floor_ms else "~2.0",
+                                         "cannot be shorter than that and frac <= %.2f; the fp64 roof is approached by batches that fill the lanes: "
+                                         "65 536 rollouts (aux_large_batch_rollouts) and independent knots (aux_independent_knots)" % ("%.2f" % latency_floor_ms if latency_floor_ms else "~2.0",
                                                                      (ach_tflops / FP64_PEAK_TFLOPS) * kernel_ms / latency_floor_ms if latency_floor_ms else 0.20)},
             "dense_fx_fu": {"ms_per_step": dense_ms, "note": "the same step through od_rollout (dense 2nq x 2nq fx and 2nq x nu fu with their constant rows, what the reference's callbacks fill) instead of the compact dq3"},
             "solver_status_counts": {"converged(7)": stc[7], "other": int(sum(stc) - stc[7])},
         }
         if strong is not None:
             line["strong_scaling"] = strong
+        if aux_roll is not None:
+            Fr_, _, _ = algorithmic_flops_per_unit(aux_roll["mean_iterations"], stats)
+            aux_roll["algorithmic_tflops"] = Fr_ * aux_roll["units_per_s"] / 1e12
+            aux_roll["algorithmic_frac"] = aux_roll["algorithmic_tflops"] / FP64_PEAK_TFLOPS
+            line["aux_large_batch_rollouts"] = aux_roll
         if aux is not None:
             Fk, _, _ = algorithmic_flops_per_unit(aux["mean_iterations"], stats)
             aux["algorithmic_tflops"] = Fk * aux["units_per_s"] / 1e12
