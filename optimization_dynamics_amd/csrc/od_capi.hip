@@ -320,6 +320,113 @@ __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward(IlqrArgs a) {
   }
 }
 
+
+// Round 3: TB CONSECUTIVE TRAJECTORIES PER WORKGROUP.  The kernel above reads one trajectory's matrices: in the batch-minor
+// layout (element e of knot k at e*K + k) its 256 threads touch 256 different 64-byte segments for 8 useful bytes each --
+// 470 loads per knot, 8x the useful HBM traffic, and that traffic was its time (rocket n = 12, m = 3, T = 60, 4096
+// trajectories: 2.54 ms per call, 35 % of an iLQR iteration of BASELINE config 5).  Here thread (s, j) = (tid / TB, tid % TB)
+// works on trajectory b0 + j, so the TB threads of a slot read one full segment; every matrix lives in LDS as [entry][j];
+// the entries of an operation are dealt to the 256 / TB slots.  Same sums in the same order as above: same results.
+template <int TB>
+__global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward_tb(IlqrArgs a) {
+  extern __shared__ double od_il_lds[];
+  constexpr int NS = OD_IL_THREADS / TB;
+  const int n = a.n, m = a.m, tid = threadIdx.x, j = tid % TB, s = tid / TB;
+  const int nn = n * n, nm = n * m, mm = m * m;
+  const long b = (long)blockIdx.x * TB + j;
+  const bool live = b < a.B;
+  const long bb = live ? b : a.B - 1;                   // (threads past the batch repeat its last trajectory, store nothing)
+  double* p = od_il_lds;
+  auto take = [&](int cnt) { double* q = p; p += (size_t)cnt * TB; return q; };
+  double *Vxx = take(nn), *At = take(nn), *W = take(nn), *Qxx = take(nn), *Bt = take(nm), *WB = take(nm), *Qux = take(nm), *Kt = take(nm),
+         *QK = take(nm), *Quu = take(mm), *L = take(mm), *Vx = take(n), *Qx = take(n), *Qu = take(m), *kt = take(m), *Quuk = take(m);
+  double* dVs = take(2);
+  int* okf = (int*)take(1);
+#define OD_E(M_, e) M_[(e) * TB + j]
+  for (int e = s; e < nn; e += NS) OD_E(Vxx, e) = a.VxxT.at(e, bb);
+  for (int e = s; e < n; e += NS) OD_E(Vx, e) = a.VxT.at(e, bb);
+  if (s == 0) { OD_E(dVs, 0) = 0.0; OD_E(dVs, 1) = 0.0; okf[j] = 1; }
+  __syncthreads();
+  for (int t = a.T - 1; t >= 0; --t) {
+    const long kk = (long)t * a.B + bb;
+    for (int e = s; e < nn; e += NS) OD_E(At, e) = a.A.at(e, kk);
+    for (int e = s; e < nm; e += NS) OD_E(Bt, e) = a.Bm.at(e, kk);
+    __syncthreads();
+    // W = Vxx A (n x n), WB = Vxx B (n x m)
+    for (int e = s; e < nn; e += NS) { const int i = e % n, c = e / n; double sm = 0; for (int l = 0; l < n; ++l) sm += OD_E(Vxx, i + n * l) * OD_E(At, l + n * c); OD_E(W, e) = sm; }
+    for (int e = s; e < nm; e += NS) { const int i = e % n, c = e / n; double sm = 0; for (int l = 0; l < n; ++l) sm += OD_E(Vxx, i + n * l) * OD_E(Bt, l + n * c); OD_E(WB, e) = sm; }
+    __syncthreads();
+    // Qxx = lxx + A'W, Qux = lux + B'W, Quu = luu + B'WB, Qx = lx + A'Vx, Qu = lu + B'Vx
+    for (int e = s; e < nn; e += NS) { const int i = e % n, c = e / n; double sm = a.lxx.at(e, kk); for (int l = 0; l < n; ++l) sm += OD_E(At, l + n * i) * OD_E(W, l + n * c); OD_E(Qxx, e) = sm; }
+    for (int e = s; e < nm; e += NS) { const int i = e % m, c = e / m; double sm = a.lux.at(e, kk); for (int l = 0; l < n; ++l) sm += OD_E(Bt, l + n * i) * OD_E(W, l + n * c); OD_E(Qux, e) = sm; }
+    for (int e = s; e < mm; e += NS) { const int i = e % m, c = e / m; double sm = a.luu.at(e, kk); for (int l = 0; l < n; ++l) sm += OD_E(Bt, l + n * i) * OD_E(WB, l + n * c); OD_E(Quu, e) = sm; }
+    for (int e = s; e < n; e += NS) { double sm = a.lx.at(e, kk); for (int l = 0; l < n; ++l) sm += OD_E(At, l + n * e) * OD_E(Vx, l); OD_E(Qx, e) = sm; }
+    for (int e = s; e < m; e += NS) { double sm = a.lu.at(e, kk); for (int l = 0; l < n; ++l) sm += OD_E(Bt, l + n * e) * OD_E(Vx, l); OD_E(Qu, e) = sm; }
+    __syncthreads();
+    // Cholesky of Quu + reg I (m <= 12: one thread per trajectory)
+    if (s == 0) {
+      for (int i = 0; i < mm; ++i) OD_E(L, i) = OD_E(Quu, i);
+      for (int i = 0; i < m; ++i) OD_E(L, i + m * i) += a.reg;
+      for (int c = 0; c < m; ++c) {
+        double d = OD_E(L, c + m * c);
+        for (int l = 0; l < c; ++l) d -= OD_E(L, c + m * l) * OD_E(L, c + m * l);
+        if (!(d > 0.0)) { okf[j] = 0; d = 1e-12; }
+        d = sqrt(d);
+        OD_E(L, c + m * c) = d;
+        for (int i = c + 1; i < m; ++i) { double sx = OD_E(L, i + m * c); for (int l = 0; l < c; ++l) sx -= OD_E(L, i + m * l) * OD_E(L, c + m * l); OD_E(L, i + m * c) = sx / d; }
+      }
+    }
+    __syncthreads();
+    // K = -(Quu+reg)^{-1} Qux (column c, in place in Kt), k = -(Quu+reg)^{-1} Qu (c = n, in place in kt)
+    for (int c = s; c <= n; c += NS) {
+      double* y = (c < n) ? (Kt + (size_t)m * c * TB) : kt;
+      for (int i = 0; i < m; ++i) y[i * TB + j] = (c < n) ? OD_E(Qux, i + m * c) : OD_E(Qu, i);
+      for (int i = 0; i < m; ++i) { double sx = y[i * TB + j]; for (int l = 0; l < i; ++l) sx -= OD_E(L, i + m * l) * y[l * TB + j]; y[i * TB + j] = sx / OD_E(L, i + m * i); }
+      for (int i = m - 1; i >= 0; --i) { double sx = y[i * TB + j]; for (int l = i + 1; l < m; ++l) sx -= OD_E(L, l + m * i) * y[l * TB + j]; y[i * TB + j] = sx / OD_E(L, i + m * i); }
+      for (int i = 0; i < m; ++i) y[i * TB + j] = -y[i * TB + j];
+    }
+    __syncthreads();
+    if (live) {
+      for (int e = s; e < nm; e += NS) a.K.at(e, kk) = OD_E(Kt, e);
+      for (int e = s; e < m; e += NS) a.k.at(e, kk) = OD_E(kt, e);
+    }
+    for (int e = s; e < m; e += NS) { double sx = 0; for (int l = 0; l < m; ++l) sx += OD_E(Quu, e + m * l) * OD_E(kt, l); OD_E(Quuk, e) = sx; }   // Quu k (Quu without reg)
+    for (int e = s; e < nm; e += NS) { const int i = e % m, c = e / m; double sx = 0; for (int l = 0; l < m; ++l) sx += OD_E(Quu, i + m * l) * OD_E(Kt, l + m * c); OD_E(QK, e) = sx; }
+    __syncthreads();
+    if (s == 0) {
+      double d1 = 0, d2 = 0;
+      for (int i = 0; i < m; ++i) { d1 += OD_E(kt, i) * OD_E(Qu, i); d2 += 0.5 * OD_E(kt, i) * OD_E(Quuk, i); }
+      OD_E(dVs, 0) += d1; OD_E(dVs, 1) += d2;
+    }
+    // value function update: new Vx into Qx's place (Qx is read by its own entry only), new Vxx into W
+    for (int e = s; e < n; e += NS) {
+      double sx = OD_E(Qx, e);
+      for (int l = 0; l < m; ++l) sx += OD_E(Kt, l + m * e) * (OD_E(Quuk, l) + OD_E(Qu, l)) + OD_E(Qux, l + m * e) * OD_E(kt, l);
+      OD_E(Vx, e) = sx;
+    }
+    for (int e = s; e < nn; e += NS) {
+      const int i = e % n, c = e / n;
+      double sx = OD_E(Qxx, e);
+      for (int l = 0; l < m; ++l) sx += OD_E(Kt, l + m * i) * (OD_E(QK, l + m * c) + OD_E(Qux, l + m * c)) + OD_E(Qux, l + m * i) * OD_E(Kt, l + m * c);
+      OD_E(W, e) = sx;
+    }
+    __syncthreads();
+    for (int e = s; e < nn; e += NS) {
+      const int i = e % n, c = e / n;
+      OD_E(Vxx, e) = (i == c) ? OD_E(W, e) : 0.5 * (OD_E(W, i + n * c) + OD_E(W, c + n * i));
+    }
+    __syncthreads();
+  }
+  if (s == 0 && live) {
+    a.dV.at(0, b) = OD_E(dVs, 0);
+    a.dV.at(1, b) = OD_E(dVs, 1);
+    if (a.status.ok()) a.status.at(0, b) = okf[j];
+  }
+#undef OD_E
+}
+// doubles of LDS per trajectory of a workgroup
+static inline size_t od_il_lds_per_traj(int n, int m) { return (size_t)4 * n * n + 5 * n * m + 2 * m * m + 2 * n + 3 * m + 2 + 1; }
+
 #else
 // host test build (threads run one after the other, no workgroup cooperation): one lane per trajectory
 __global__ __launch_bounds__(OD_BLOCK) void k_ilqr_backward_serial(IlqrArgs a) {
@@ -930,7 +1037,20 @@ int od_ilqr_backward(od_handle h, long B, int T, int n, int m, const void* A, co
   a.K = mkview<double>(K, m * n, Kn, L); a.k = mkview<double>(k, m, Kn, L);
   a.dV = mkview<double>(dV, 2, B, L); a.status = mkview<int>(status, 1, B, L);
 #if defined(__HIPCC__)
-  hipLaunchKernelGGL(k_ilqr_backward, dim3((unsigned)B), dim3(OD_IL_THREADS), 0, h->stream, a);
+  {
+    // batch-minor data: TB consecutive trajectories per workgroup (coalesced), as many as 64 KB of LDS hold; batch-major data
+    // (a trajectory's entries are contiguous): the one-trajectory kernel
+    const size_t per = od_il_lds_per_traj(n, m) * sizeof(double);
+    // ... but never fewer than 1024 workgroups while the batch allows (a workgroup of TB trajectories takes TB times as long:
+    // measured on the rocket, T = 60, ms per iLQR iteration: 4096 trajectories 7.10 (one per workgroup) / 6.48 (two) / 5.67 (four) / 6.00 (eight);
+    // 1024 trajectories 4.30 (one) / 4.53 (two) / 5.02 (eight))
+    int tb = (L != OD_LAYOUT_BATCH_MINOR) ? 1 : (8 * per <= 65536 ? 8 : (4 * per <= 65536 ? 4 : (2 * per <= 65536 ? 2 : 1)));
+    while (tb > 1 && B / tb < 1024) tb >>= 1;
+    if (tb == 8) hipLaunchKernelGGL((k_ilqr_backward_tb<8>), od_grid(B, 8), dim3(OD_IL_THREADS), 8 * per, h->stream, a);
+    else if (tb == 4) hipLaunchKernelGGL((k_ilqr_backward_tb<4>), od_grid(B, 4), dim3(OD_IL_THREADS), 4 * per, h->stream, a);
+    else if (tb == 2) hipLaunchKernelGGL((k_ilqr_backward_tb<2>), od_grid(B, 2), dim3(OD_IL_THREADS), 2 * per, h->stream, a);
+    else hipLaunchKernelGGL(k_ilqr_backward, dim3((unsigned)B), dim3(OD_IL_THREADS), 0, h->stream, a);
+  }
 #else
   hipLaunchKernelGGL(k_ilqr_backward_serial, od_grid(B, OD_BLOCK), dim3(OD_BLOCK), 0, h->stream, a);
 #endif

@@ -60,6 +60,25 @@ def check_backward_and_forward(oracle, lib, device):
     assert (u_expect - Uc[:, t, a * B + b]).abs().max().item() < 1e-12
 
 
+def check_backward_trajectories_per_workgroup(lib, device, sizes=(2304, 4608, 9001), T=6):
+    """od_ilqr_backward gives a workgroup 2 / 4 / 8 consecutive trajectories once the batch keeps 1024 workgroups busy (csrc/od_capi.hip:
+    k_ilqr_backward_tb): gains, feed-forward terms, expected decrease and status identical to the one-trajectory-per-workgroup kernel
+    (the same trajectories in batches of 500), ragged last workgroup included"""
+    for B in sizes:
+        im, obj, x1, U0 = cartpole_problem(lib, device, B, T, seed=3)
+        solver = IL.ILQR(im, obj, T)
+        x1t, Ut = torch.tensor(x1, device=device), torch.tensor(U0, device=device)
+        X, A, Bm, st = solver.linearize(x1t, Ut)
+        lam = torch.zeros(4, B, dtype=torch.float64, device=device)
+        quad = obj.expansion(X, Ut, lam, 1.0)
+        K, k, dV, bst = solver.backward(A, Bm, quad, 1e-6)
+        assert (bst == 1).all() and torch.isfinite(K).all()
+        for b0 in range(0, B, 500):
+            sl = slice(b0, min(B, b0 + 500))
+            Ks, ks, dVs, bs = solver.backward(A[..., sl], Bm[..., sl], tuple(q[..., sl].contiguous() for q in quad), 1e-6)
+            assert torch.equal(Ks, K[..., sl]) and torch.equal(ks, k[..., sl]) and torch.equal(dVs, dV[:, sl]) and torch.equal(bs, bst[sl]), (B, b0)
+
+
 def check_solver_decreases_cost(lib, device, B=8, T=25):
     im, obj, x1, U0 = cartpole_problem(lib, device, B, T, seed=1)
     solver = IL.ILQR(im, obj, T)

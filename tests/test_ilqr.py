@@ -24,6 +24,11 @@ def test_one_bad_trajectory_does_not_hurt_the_batch_gpu(gpu_lib):
 
 
 @pytest.mark.gpu
+def test_backward_trajectories_per_workgroup_gpu(gpu_lib):
+    C.check_backward_trajectories_per_workgroup(gpu_lib, "cuda:0")
+
+
+@pytest.mark.gpu
 def test_backward_forward_gpu(oracle, gpu_lib):
     C.check_backward_and_forward(oracle, gpu_lib, "cuda:0")
 
