@@ -513,8 +513,11 @@ struct od_handle_s {
   double* work;    // device workspace: gradient iterates handed from pass 1 to pass 2
   size_t work_elems;
   long grad_knots; // knots of the last gradient pass (the hand-over is batch-minor with that stride); 0 = none
-  double* stage;   // device staging for the host scalar path
+  double* stage;   // device staging for the host-pointer entry points (rocket, bundle)
   size_t stage_elems;
+  double* hstage;  // pinned, device-mapped host staging of od_f_host / od_fx_host / od_fu_host
+  double* hstage_dev;
+  size_t hstage_elems;
 };
 
 namespace {
@@ -838,6 +841,9 @@ int od_create(int model, int dtype, const od_options* opts, double dt, od_handle
   h->grad_knots = 0;
   h->stage = nullptr;
   h->stage_elems = 0;
+  h->hstage = nullptr;
+  h->hstage_dev = nullptr;
+  h->hstage_elems = 0;
   *out = h;
   return OD_OK;
 }
@@ -845,6 +851,7 @@ int od_create(int model, int dtype, const od_options* opts, double dt, od_handle
 int od_destroy(od_handle h) {
   if (!h) return OD_OK;
   if (h->stage) (void)hipFree(h->stage);
+  if (h->hstage) (void)hipHostFree(h->hstage);
   if (h->work) (void)hipFree(h->work);
   delete h;
   return OD_OK;
@@ -1225,32 +1232,36 @@ int od_soc_project(od_handle h, long B, const void* u, void* uproj, void* duproj
 }
 
 // ---- host scalar path ------------------------------------------------------------------------
+// One knot on host vectors.  The staging area is PINNED, DEVICE-MAPPED HOST MEMORY (hipHostMalloc, coherent): the kernels read
+// x, u and write d / fx / fu straight across the link, so a call is two host memcpys of a few hundred bytes, the launches and one
+// synchronisation -- no hipMemcpy at all (round 2 staged through device memory with up to five small copies: 51 / 60 / 55 us per
+// f / fx / fu call; now see DESIGN.md section 6).
 static int host_call(od_handle h, const double* x, const double* u, double* d, double* dx, double* du) {
   if (int rc = check_mech(h, "od_f_host")) return rc;
   const int n = 2 * h->vt->nq, nu = h->vt->nu;
   if (!x || (nu > 0 && !u)) return fail(OD_ERR_INVALID, "od_f_host / od_fx_host / od_fu_host: null x / u");
   if (!d && !dx && !du) return fail(OD_ERR_INVALID, "od_f_host / od_fx_host / od_fu_host: no output buffer");
   const size_t need = (size_t)n + nu + n + (size_t)n * n + (size_t)n * nu;
-  if (h->stage_elems < need) {
-    if (h->stage) (void)hipFree(h->stage);
-    OD_HIP(hipMalloc((void**)&h->stage, need * sizeof(double)));
-    h->stage_elems = need;
+  if (h->hstage_elems < need) {
+    if (h->hstage) (void)hipHostFree(h->hstage);
+    h->hstage = nullptr; h->hstage_elems = 0;
+    OD_HIP(hipHostMalloc((void**)&h->hstage, need * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    OD_HIP(hipHostGetDevicePointer((void**)&h->hstage_dev, h->hstage, 0));
+    h->hstage_elems = need;
   }
-  double* dxp = h->stage;
-  double* dup = dxp + n;
-  double* ddp = dup + nu;
-  double* dAp = ddp + n;
-  double* dBp = dAp + (size_t)n * n;
-  OD_HIP(hipMemcpyAsync(dxp, x, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  if (nu) OD_HIP(hipMemcpyAsync(dup, u, nu * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  double* hx = h->hstage;                     // host view
+  double* gx = h->hstage_dev;                 // the same bytes as the device sees them
+  const size_t ou = n, od_ = ou + nu, oA = od_ + n, oB = oA + (size_t)n * n;
+  std::memcpy(hx, x, n * sizeof(double));
+  if (nu) std::memcpy(hx + ou, u, nu * sizeof(double));
   const int want_grad = (dx || du) ? 1 : 0;
-  int rc = run_step(h, "od_f_host", 1, dxp, dup, d ? ddp : nullptr, dx ? dAp : nullptr, du ? dBp : nullptr, nullptr,
+  int rc = run_step(h, "od_f_host", 1, gx, gx + ou, d ? gx + od_ : nullptr, dx ? gx + oA : nullptr, du ? gx + oB : nullptr, nullptr,
                     nullptr, nullptr, want_grad);
   if (rc) return rc;
-  if (d) OD_HIP(hipMemcpyAsync(d, ddp, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (dx) OD_HIP(hipMemcpyAsync(dx, dAp, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (du) OD_HIP(hipMemcpyAsync(du, dBp, (size_t)n * nu * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   OD_HIP(hipStreamSynchronize(h->stream));
+  if (d) std::memcpy(d, hx + od_, n * sizeof(double));
+  if (dx) std::memcpy(dx, hx + oA, (size_t)n * n * sizeof(double));
+  if (du) std::memcpy(du, hx + oB, (size_t)n * nu * sizeof(double));
   return OD_OK;
 }
 

@@ -35,6 +35,10 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return hipSuccess; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+enum { hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000 };
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n); return hipSuccess; }
+inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
+inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
