@@ -22,7 +22,7 @@ def test_step_and_compact_outputs_consistent(emu_lib, name):
     P.check_step_only_and_compact(emu_lib, "cpu", name, 64)
 
 
-@pytest.mark.parametrize("name", ["cartpole_friction", "hopper"])
+@pytest.mark.parametrize("name", ["cartpole_friction", "hopper", "planar_push"])
 def test_batch_major_layout_identical(emu_lib, name):
     P.check_layouts(emu_lib, "cpu", name, 96)
 
