@@ -15,7 +15,7 @@ def test_models_with_cooperative_kernels(emu_lib):
     from optimization_dynamics_amd import models
     hop, acro = P.make_im("hopper", emu_lib, "cpu"), P.make_im("acrobot_impact", emu_lib, "cpu")
     uses = emu_lib.cdll.od_uses_cooperative
-    assert uses(hop._h, 4096) == 1 and uses(hop._h, 8192) == 1 and uses(hop._h, 16384) == 0       # automatic: small batches (16 lanes per problem up to 4096, 8 lanes up to 8192)
+    assert uses(hop._h, 4096) == 1 and uses(hop._h, 16384) == 1 and uses(hop._h, 16385) == 0      # automatic: small batches (16 lanes per problem up to 4096, 8 lanes up to 16 384)
     assert uses(acro._h, 1024) == 1 and uses(acro._h, 4096) == 1 and uses(acro._h, 4097) == 0      # two contacts: up to 4096
     acro.set_cooperative(2); assert uses(acro._h, 65536) == 1
     hop.set_cooperative(1); assert uses(hop._h, 64) == 0

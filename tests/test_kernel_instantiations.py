@@ -41,6 +41,13 @@ def test_rollout_8192_eight_lanes_per_problem(oracle, gpu_lib):
 
 
 @pytest.mark.gpu
+def test_rollout_12000_eight_lanes_two_wavefronts_per_simd(oracle, gpu_lib):
+    """B = 12 000: k_rollout_state_coop3<Coop3_hopper, 2> (the 256-register build, 8193..16 384 rollouts); reference mapping: batches
+    of 6000 through k_rollout_state_coop3<Coop3_hopper, 1> -- one kernel form, two builds: identical results"""
+    P.check_rollout_instantiation(oracle, gpu_lib, "cuda:0", 12000, 10, 6000, t_chain=(0, 9))
+
+
+@pytest.mark.gpu
 def test_rollout_4100_eight_lanes_ragged(oracle, gpu_lib):
     """B = 4100: the 8-lane form with a ragged last wavefront; reference: batches of 2050 through the 16-lane form (rpw = 4)"""
     P.check_rollout_instantiation(oracle, gpu_lib, "cuda:0", 4100, 12, 2050, t_chain=(0, 11), same_form=False)
