@@ -328,6 +328,14 @@ def _emit(m: ModelSpec, d: Derived) -> str:
     w("  // replicated copies of the contact forces the dynamics rows (gather_r) / their Jacobian (gather_rz) read\n")
     gather("gather_r", fv_r)
     gather("gather_rz", fv_rz)
+    w("  // the same copies from per-role arrays (lane-parallel line-search trials, od_coop3.h::c3_trials_lanes)\n")
+    w("  template <class V> OD_HD static void scatter_r(const V* P0, const V* P1, const V* P2, V* zr) {\n")
+    for k in fv_r:
+        lane, fld = lane_of_z(k)
+        w("    zr[%d] = %s[%d];\n" % (k, fld, lane))
+    w("  }\n")
+    arr("E1ROWA", RSL + RV1)
+    arr("E1ROWB", [-1] * NC + RV2)
     w("  // aux expressions of the lane: -(phi_i) for contact i, the first / second tangential velocity for cone c (rows of the\n")
     w("  // serial residual evaluated with s_i = s_b = 0)\n")
     for nm, rows in (("pick_e1a", RSL + RV1), ("pick_e1b", [-1] * NC + RV2)):

@@ -39,19 +39,23 @@ struct Vec8 {
   inline Vec8 operator op(const Vec8& a, const Vec8& b) { Vec8 r; for (int i = 0; i < 8; ++i) r.v[i] = a.v[i] op b.v[i]; return r; } \
   inline Vec8 operator op(const Vec8& a, double b) { Vec8 r; for (int i = 0; i < 8; ++i) r.v[i] = a.v[i] op b; return r; }              \
   inline Vec8 operator op(double a, const Vec8& b) { Vec8 r; for (int i = 0; i < 8; ++i) r.v[i] = a op b.v[i]; return r; }
-OD_V8_BIN(+) OD_V8_BIN(-) OD_V8_BIN(*)
+OD_V8_BIN(+) OD_V8_BIN(-) OD_V8_BIN(*) OD_V8_BIN(/)
 #undef OD_V8_BIN
 inline Vec8 operator-(const Vec8& a) { Vec8 r; for (int i = 0; i < 8; ++i) r.v[i] = -a.v[i]; return r; }
 #define OD_V8_CMP(op)                                                                                                \
   inline Mask8 operator op(const Vec8& a, const Vec8& b) { Mask8 r; for (int i = 0; i < 8; ++i) r.m[i] = a.v[i] op b.v[i]; return r; } \
   inline Mask8 operator op(const Vec8& a, double b) { Mask8 r; for (int i = 0; i < 8; ++i) r.m[i] = a.v[i] op b; return r; }
-OD_V8_CMP(>) OD_V8_CMP(<) OD_V8_CMP(!=)
+OD_V8_CMP(>) OD_V8_CMP(<) OD_V8_CMP(!=) OD_V8_CMP(<=) OD_V8_CMP(==)
 #undef OD_V8_CMP
 inline Mask8 operator&&(const Mask8& a, const Mask8& b) { Mask8 r; for (int i = 0; i < 8; ++i) r.m[i] = a.m[i] && b.m[i]; return r; }
+inline Mask8 operator!(const Mask8& a) { Mask8 r; for (int i = 0; i < 8; ++i) r.m[i] = !a.m[i]; return r; }
 inline Mask8 operator||(const Mask8& a, const Mask8& b) { Mask8 r; for (int i = 0; i < 8; ++i) r.m[i] = a.m[i] || b.m[i]; return r; }
 inline Vec8 od_rcp(const Vec8& a) { Vec8 r; for (int i = 0; i < 8; ++i) r.v[i] = od_rcp(a.v[i]); return r; }
 inline Vec8 od_rsqrt(const Vec8& a) { Vec8 r; for (int i = 0; i < 8; ++i) r.v[i] = od_rsqrt(a.v[i]); return r; }
 inline Vec8 od_sqrt(const Vec8& a) { Vec8 r; for (int i = 0; i < 8; ++i) r.v[i] = od_sqrt(a.v[i]); return r; }
+inline Vec8 od_sin(const Vec8& a) { Vec8 r; for (int i = 0; i < 8; ++i) r.v[i] = od_sin(a.v[i]); return r; }
+inline Vec8 od_cos(const Vec8& a) { Vec8 r; for (int i = 0; i < 8; ++i) r.v[i] = od_cos(a.v[i]); return r; }
+template <int Q> inline Vec8 od_rootinv(const Vec8& a) { Vec8 r; for (int i = 0; i < 8; ++i) r.v[i] = od_rootinv<Q>(a.v[i]); return r; }
 inline Vec8 od_abs(const Vec8& a) { Vec8 r; for (int i = 0; i < 8; ++i) r.v[i] = od_abs(a.v[i]); return r; }
 inline Vec8 od_max(const Vec8& a, const Vec8& b) { Vec8 r; for (int i = 0; i < 8; ++i) r.v[i] = od_max(a.v[i], b.v[i]); return r; }
 inline Vec8 od_fmax(const Vec8& a, const Vec8& b) { Vec8 r; for (int i = 0; i < 8; ++i) r.v[i] = od_fmax(a.v[i], b.v[i]); return r; }
@@ -89,6 +93,11 @@ struct Row8Emu {
   static V vmin(const V& a, const V& b) { return od_fmin(a, b); }
   static bool first_lane() { return true; }
   static void arrived(const double&) {}
+  // lane-parallel line-search trials: lane g of the group takes step alpha 2^-g
+  static V lane_ldexp(double a) { V r; for (int i = 0; i < 8; ++i) r.v[i] = od_ldexp(a, -i); return r; }
+  static B lane_below(int n) { B r; for (int i = 0; i < 8; ++i) r.m[i] = i < n; return r; }
+  static unsigned grp_ballot(const B& b) { unsigned m = 0; for (int i = 0; i < 8; ++i) m |= (b.m[i] ? 1u : 0u) << i; return m; }
+  static double opaque(double x) { return x; }
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -140,6 +149,11 @@ struct Row8Dev {
   __device__ __forceinline__ static double vmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
   __device__ __forceinline__ static bool first_lane() { return lane() == 0; }
   __device__ __forceinline__ static void arrived(const double& x) { asm volatile("" ::"v"(x)); }
+  __device__ __forceinline__ static V lane_ldexp(double a) { return od_ldexp(a, -lane()); }
+  __device__ __forceinline__ static B lane_below(int n) { return lane() < n; }
+  // the 8 lanes' predicate bits of this group (under divergence: of the groups that execute)
+  __device__ __forceinline__ static unsigned grp_ballot(bool b) { return (unsigned)(__builtin_amdgcn_ballot_w64(b) >> (threadIdx.x & 56)) & 0xFFu; }
+  __device__ __forceinline__ static double opaque(double x) { asm volatile("" : "+v"(x)); return x; }
 };
 #endif
 
@@ -603,12 +617,104 @@ OD_HD double c3_centering(const C3Lanes<CM, RO>& L, const C3Vec<CM::NQ, typename
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Eight line-search trials at once (as od_coop.h::coop_trials_lanes does sixteen): lane g of the group evaluates
+// r(z - a_g D; theta, 0) for ITS step a_g = alpha 2^-g -- the whole residual in one lane, every contact and cone in turn,
+// with the arithmetic of c3_eval_r / c3_viol, so that a trial is accepted here exactly when the cooperative evaluation of
+// the same step accepts it.
+// ---------------------------------------------------------------------------------------------------------------
+template <class CM, class RO, int R = 0>
+OD_HD void c3_fetch_roles(const C3Vec<CM::NQ, typename RO::V>& z, typename RO::V (*P)[CM::NC + CM::NK > 0 ? CM::NC + CM::NK : 1]) {
+  if constexpr (R < CM::NC + CM::NK) {
+    using V = typename RO::V;
+    P[0][R] = V(RO::template bc<R>(z.P0)); P[1][R] = V(RO::template bc<R>(z.P1)); P[2][R] = V(RO::template bc<R>(z.P2));
+    P[3][R] = V(RO::template bc<R>(z.D0)); P[4][R] = V(RO::template bc<R>(z.D1)); P[5][R] = V(RO::template bc<R>(z.D2));
+    c3_fetch_roles<CM, RO, R + 1>(z, P);
+  }
+}
+
+template <class CM, class RO>
+OD_HD typename RO::B c3_trials_lanes(const C3Lanes<CM, RO>& L, const double* th, const double* pre, const C3Vec<CM::NQ, typename RO::V>& z,
+                                     const C3Vec<CM::NQ, typename RO::V>& D, typename RO::V aj, double r_vio, double k_vio) {
+  using M = typename CM::M;
+  using V = typename RO::V;
+  constexpr int NQ = CM::NQ, NR = (CM::NC + CM::NK) > 0 ? (CM::NC + CM::NK) : 1;
+  const double inf = __builtin_inf();
+  V Z[6][NR], DD[6][NR];
+  c3_fetch_roles<CM, RO>(z, Z);
+  c3_fetch_roles<CM, RO>(D, DD);
+  V zr[M::NZ], rr[M::NZ], thv[M::NTH], prev[M::NPRE], trv[M::NTR];
+#pragma unroll
+  for (int i = 0; i < M::NZ; ++i) zr[i] = V(0.0);
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) zr[CM::ZQ[k]] = V(z.q[k]) - aj * V(D.q[k]);
+#pragma unroll
+  for (int f = 0; f < 6; ++f) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) Z[f][i] = Z[f][i] - aj * DD[f][i];
+  }
+  CM::scatter_r(Z[0], Z[1], Z[2], zr);
+#pragma unroll
+  for (int i = 0; i < M::NTH; ++i) thv[i] = V(th[i]);
+#pragma unroll
+  for (int i = 0; i < M::NPRE; ++i) prev[i] = V(pre[i]);
+  M::eval_r(zr, thv, prev, trv, rr);
+  V ve = V(0.0), se = V(0.0);
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) { const V a = od_abs(rr[CM::RDYN[k]]); ve = od_fmax(ve, a); se = se + a; }
+  double g[CM::NK > 0 ? CM::NK : 1], gc[CM::NK > 0 ? CM::NK : 1];
+  if constexpr (CM::NK > 0) CM::eval_gcoef(th, g, gc);
+  V de = V(0.0), dk = V(0.0);
+#pragma unroll
+  for (int i = 0; i < CM::NC + CM::NK; ++i) {
+    const bool cone = i >= CM::NC;
+    const V &P0 = Z[0][i], &P1 = Z[1][i], &P2 = Z[2][i], &D0 = Z[3][i], &D1 = Z[4][i], &D2 = Z[5][i];
+    const double c_s = RO::opaque(cone ? 0.0 : 1.0), c_va = RO::opaque(CM::CVA[i]), c_vb = RO::opaque(CM::CVB[i]);
+    const V r1a = rr[CM::E1ROWA[i]] + c_s * D0 + c_va * D1;
+    V r1b = V(0.0);
+    if constexpr (CM::DIM3) {
+      if (CM::E1ROWB[i] >= 0) r1b = rr[CM::E1ROWB[i] >= 0 ? CM::E1ROWB[i] : 0] + c_vb * D2;
+      else r1b = V(0.0) + c_vb * D2;
+    }
+    V r2 = V(0.0);
+    if constexpr (CM::NK > 0) {
+      if (cone) {
+        const int c = i - CM::NC;
+        const double c_psi = RO::opaque(1.0);
+        V gp = V(0.0);
+        if (CM::SH > 0 && ((CM::PARTNER_BITS >> i) & 1u)) gp = V(g[c]) * Z[0][i - CM::SH >= 0 ? i - CM::SH : 0];
+        r2 = c_psi * P0 + gp + V(gc[c]);
+      }
+    }
+    V rA = P0 * D0 + P1 * D1;
+    const V rB1 = P0 * D1 + P1 * D0;
+    V rB2 = V(0.0);
+    if constexpr (CM::DIM3) {
+      rA = rA + P2 * D2;
+      rB2 = P0 * D2 + P2 * D0;
+    }
+    const V a1 = od_abs(r1a), a1b = od_abs(r1b), a2 = od_abs(r2), aA = od_abs(rA), aB1 = od_abs(rB1), aB2 = od_abs(rB2);
+    V e = od_fmax(od_fmax(a1, a1b), a2);
+    const V es = a1 + a1b + a2;
+    e = RO::sel(es != es, inf, e);
+    V k = od_fmax(od_fmax(aA, aB1), aB2);
+    const V ks = aA + aB1 + aB2;
+    k = RO::sel(ks != ks, inf, k);
+    de = RO::vmax(de, e);
+    dk = RO::vmax(dk, k);
+  }
+  de = od_fmax(de, ve);
+  const typename RO::B r_nan = (se != se) || (de == inf), k_nan = (dk == inf);
+  const typename RO::B r_ok = (de <= r_vio) && !r_nan, k_ok = (dk <= k_vio) && !k_nan;
+  return r_ok || k_ok;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // one predictor-corrector iteration (od_solver.h::ip_iteration), line search included
 // ---------------------------------------------------------------------------------------------------------------
 template <class CM, class RO>
-OD_HD void c3_iteration(const C3Lanes<CM, RO>& L, const Opts<double>& o, const double* th, const double* pre, double* tr,
+OD_HD bool c3_iteration(const C3Lanes<CM, RO>& L, const Opts<double>& o, const double* th, const double* pre, double* tr,
                         C3Vec<CM::NQ, typename RO::V>& z, C3Res<CM::NQ, typename RO::V>& r, double& r_vio, double& k_vio,
-                        double& reg_prev, int& status, C3Fact<CM, RO>& f) {
+                        double& reg_prev, int& status, C3Fact<CM, RO>& f, int& ls_hint) {
   using V = typename RO::V;
   using Vec = C3Vec<CM::NQ, V>;
   using Res = C3Res<CM::NQ, V>;
@@ -641,24 +747,61 @@ OD_HD void c3_iteration(const C3Lanes<CM, RO>& L, const Opts<double>& o, const d
   const double vio = od_fmax(r_vio, k_vio);
   const double tau = 1.0 - od_fmin(o.eps_min, vio * vio);
   double alpha = c3_step_length<CM, RO>(L, sp, z, D, tau, od_fmin(tau, 0.99));
-  // backtracking until either violation does not increase (od_solver.h::line_search, sequential form)
-  Vec zc;
-  Res rc;
-  double r_c = 0.0, k_c = 0.0;
-  for (int ls = 0; ls < o.max_ls; ++ls) {
+  // backtracking until either violation does not increase (od_solver.h::line_search), every trial in turn.  The lane-parallel
+  // rounds of od_coop.h::coop_iteration exist here too (OD_EXPERIMENT_C3_PARALLEL_LS: the 8 lanes of the group each try a
+  // step size, c3_trials_lanes): bit-identical results (profiles/r3_hash_c3_parallel_ls.json), planar push unchanged,
+  // hopper rollouts 8 % (8192) to 48 % (>= 16 384, spills at two wavefronts per SIMD) slower -- profiles/r3_c3_parallel_ls_ab.json
+  Vec zc = z;
+  Res rc = r;
+  double r_c = r_vio, k_c = k_vio;
+  auto trial = [&](double a) {
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) zc.q[k] = z.q[k] - alpha * D.q[k];
-    zc.P0 = z.P0 - alpha * D.P0; zc.P1 = z.P1 - alpha * D.P1; zc.P2 = z.P2 - alpha * D.P2;
-    zc.D0 = z.D0 - alpha * D.D0; zc.D1 = z.D1 - alpha * D.D1; zc.D2 = z.D2 - alpha * D.D2;
+    for (int k = 0; k < NQ; ++k) zc.q[k] = z.q[k] - a * D.q[k];
+    zc.P0 = z.P0 - a * D.P0; zc.P1 = z.P1 - a * D.P1; zc.P2 = z.P2 - a * D.P2;
+    zc.D0 = z.D0 - a * D.D0; zc.D1 = z.D1 - a * D.D1; zc.D2 = z.D2 - a * D.D2;
     c3_eval_r<CM, RO>(L, zc, th, pre, tr, rc);
     c3_viol<CM, RO>(L, rc, r_c, k_c);
-    if (r_c <= r_vio || k_c <= k_vio) break;
+    return r_c <= r_vio || k_c <= k_vio;
+  };
+#ifdef OD_EXPERIMENT_C3_PARALLEL_LS          // (measurement variant, tools/build_variants.sh)
+  const int nseq = ls_hint >= 2 ? 0 : (o.max_ls < 2 ? o.max_ls : 2);
+#else
+  const int nseq = o.max_ls;                 // shipped: every trial in turn (the lane-parallel rounds measured slower here)
+#endif
+  bool done = false;
+  int ls = 0;
+  for (; ls < nseq; ++ls) {
+    if (trial(alpha)) { done = true; break; }
     if (ls + 1 < o.max_ls) alpha *= 0.5;
   }
+#ifdef OD_EXPERIMENT_C3_PARALLEL_LS
+  if (!done && ls < o.max_ls) {
+    bool found = false;
+    for (int j0 = ls; j0 < o.max_ls && !found; j0 += 8) {
+      const typename RO::B acc = c3_trials_lanes<CM, RO>(L, th, pre, z, D, RO::lane_ldexp(alpha), r_vio, k_vio) && RO::lane_below(o.max_ls - j0);
+      const unsigned m = RO::grp_ballot(acc);
+      if (m != 0) {
+        alpha = od_ldexp(alpha, -__builtin_ctz(m));                      // first accepted trial of the round
+        found = true;
+        ls = j0 + __builtin_ctz(m);
+      } else {
+        ls = o.max_ls - 1;
+        const int left = o.max_ls - 1 - j0;                              // trials after j0: move on by 8, or to the last
+        alpha = od_ldexp(alpha, -(left < 8 ? left : 8));
+        if (left < 8) break;                                             // alpha is now the last trial's step
+      }
+    }
+    trial(alpha);                                                        // the group lands on the chosen trial
+  }
+#endif
+  // (a zero step whose trial reproduced both violations bit for bit: every further iteration would repeat this one)
+  const bool fixed_point = (alpha == 0.0) && done && ls == 0 && r_c == r_vio && k_c == k_vio;
+  ls_hint = ls;
   z = zc;
   r = rc;
   r_vio = r_c;
   k_vio = k_c;
+  return fixed_point;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -681,6 +824,7 @@ OD_HD int c3_ip_step(const C3Lanes<CM, RO>& L, const Opts<double>& o, const doub
   bool eval_done = false, grad_done = !want_grad;
   int status = OD_ST_FACTOR_OK;
   double reg_prev = 0.0;
+  int ls_hint = 0;
   iters[0] = iters[1] = 0;
   for (int it = 0;; ++it) {
     const bool req = r_vio < o.r_tol;
@@ -699,7 +843,7 @@ OD_HD int c3_ip_step(const C3Lanes<CM, RO>& L, const Opts<double>& o, const doub
       if (!last) status |= OD_ST_EVAL_OK;
     }
     if (eval_done && grad_done) break;
-    c3_iteration<CM, RO>(L, o, th, pre, tr, z, r, r_vio, k_vio, reg_prev, status, f);
+    if (c3_iteration<CM, RO>(L, o, th, pre, tr, z, r, r_vio, k_vio, reg_prev, status, f, ls_hint) && it + 1 < o.max_iter) it = o.max_iter - 1;
   }
 #pragma unroll
   for (int k = 0; k < NQ; ++k) z.q[k] = qs[k];

@@ -195,3 +195,40 @@ def test_bundle_kernel_forms(gpu_lib):
 def test_policy_rollout_eight_lane_form(gpu_lib):
     P.check_coop_policy_rollout(gpu_lib, "cuda:0", B=16, T=20, name=NAME, mode=3)
     P.check_coop_policy_rollout(gpu_lib, "cuda:0", B=16, T=20, name="hopper", mode=3)
+
+
+def test_parallel_line_search_variant_emulated(emu_lib):
+    """the lane-parallel line search of the 8-lane form (a measured, not shipped variant: DESIGN.md section 3.6) picks the trial
+    the sequential loop picks: same bits, including on jammed knots that take ten and more trials per iteration"""
+    import os, subprocess
+    from optimization_dynamics_amd import _lib
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_emu")
+    subprocess.check_call(["make", "-C", d, "-j", "8", "libod_emu_c3pls.so"], stdout=subprocess.DEVNULL)
+    var = _lib.Library(os.path.join(d, "libod_emu_c3pls.so"))
+    for name, B, opts in ((NAME, 768, {}), ("hopper", 768, {}), (NAME, 96, dict(max_ls=3)), (NAME, 96, dict(max_ls=11)), ("hopper", 96, dict(max_ls=1))):
+        X, U = W.knots(name, B, seed=97)
+        out = []
+        for lib in (emu_lib, var):
+            im = P.make_im(name, lib, "cpu")
+            if opts:
+                im.set_options(**opts)
+            im.set_cooperative(3)
+            out.append(im.step_grad(torch.tensor(X), torch.tensor(U)))
+        for a, b in zip(*out):
+            assert torch.equal(a, b), (name, opts)
+        assert out[0][4].max().item() >= 1
+    # rollouts in which iterations go past the second trial (a build that picks any other trial than the sequential loop's
+    # differs on each of these three)
+    hx, hU = W.hopper_rollout_inputs(32, 40, seed=0, u_sigma=1.0)
+    px, pU = P.planar_push_rollout_inputs(24, 26, seed=5)
+    X, U = W.knots(NAME, 512, seed=3)
+    for name, fn in (("hopper", lambda im: im.rollout(torch.tensor(hx), torch.tensor(hU))),
+                     (NAME, lambda im: im.rollout(torch.tensor(px), torch.tensor(2.0 * pU))),
+                     (NAME, lambda im: im.step_grad(torch.tensor(X), torch.tensor(10.0 * U)))):
+        out = []
+        for lib in (emu_lib, var):
+            im = P.make_im(name, lib, "cpu"); im.set_cooperative(3)
+            out.append(fn(im))
+        for a, b in zip(*out):
+            if torch.is_tensor(a):
+                assert torch.equal(a, b)

@@ -12,3 +12,10 @@ mkdir -p ../../variants/build_rd
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -DOD_EXPERIMENT_ROW_DECOUPLING -c od_model_hopper.hip -o ../../variants/build_rd/od_model_hopper.o
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../variants/libod_rowdecoupled.so $(ls build/*.o | grep -v od_model_hopper) ../../variants/build_rd/od_model_hopper.o
 echo "variants/libod_rowdecoupled.so: python tools/time_rollout.py variants/libod_rowdecoupled.so 0 4096 100"
+# lane-parallel line search in the 8-lane form (the shipped build tries every step in turn)
+mkdir -p ../../variants/build_c3pls
+for m in hopper planar_push; do
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -DOD_EXPERIMENT_C3_PARALLEL_LS -c od_model_$m.hip -o ../../variants/build_c3pls/od_model_$m.o &
+done; wait
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../variants/libod_c3pls.so $(ls build/*.o | grep -v "od_model_hopper\|od_model_planar_push") ../../variants/build_c3pls/od_model_hopper.o ../../variants/build_c3pls/od_model_planar_push.o
+echo "variants/libod_c3pls.so: OD_LIB=variants/libod_c3pls.so python tools/sweep_pp.py"

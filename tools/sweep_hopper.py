@@ -5,7 +5,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import workloads as W, parity_checks as P
 import optimization_dynamics_amd as od
-lib = od.default_library(); dev = "cuda:0"
+from optimization_dynamics_amd import _lib
+lib = _lib.Library(os.environ["OD_LIB"]) if os.environ.get("OD_LIB") else od.default_library(); dev = "cuda:0"   # (OD_LIB: a variant build)
+OUT = os.environ.get("OD_SWEEP_OUT")
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 def timeit(fn, n=5):
     fn(); torch.cuda.synchronize()
@@ -29,4 +31,4 @@ for B in (1024, 2048, 4096, 8192, 16384, 32768, 65536):
         row[nm] = timeit(f)
     out[B] = row
     print(B, {k: round(v, 3) for k, v in row.items()}, flush=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "sweep_hopper.json"), "w"), indent=1)
+json.dump(out, open(OUT or os.path.join(ROOT, "gpurun_out", "sweep_hopper.json"), "w"), indent=1)

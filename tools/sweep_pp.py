@@ -5,7 +5,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import workloads as W, parity_checks as P
 import optimization_dynamics_amd as od
-lib = od.default_library(); dev = "cuda:0"
+from optimization_dynamics_amd import _lib
+lib = _lib.Library(os.environ["OD_LIB"]) if os.environ.get("OD_LIB") else od.default_library(); dev = "cuda:0"   # (OD_LIB: a variant build)
+OUT = os.environ.get("OD_SWEEP_OUT")
 def timeit(fn, n=10):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -39,4 +41,4 @@ for B in (1, 16, 256, 2048):
         row["rollout_" + nm] = timeit(lambda: im.rollout(x1, Ud), n=5)
     out["rollout_T50_B%d" % B] = row
     print("rollout", B, {k: round(v, 4) for k, v in row.items()}, flush=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "sweep_pp.json"), "w"), indent=1)
+json.dump(out, open(OUT or os.path.join(ROOT, "gpurun_out", "sweep_pp.json"), "w"), indent=1)
