@@ -1,4 +1,4 @@
-"""one BASELINE config alone, a few calls (target of rocprofv3 / PMC runs): python tools/run_config_only.py bundle|acrobot|pp_step [reps]"""
+"""one BASELINE config alone, a few calls (target of rocprofv3 / PMC runs): python tools/run_config_only.py bundle|acrobot|pp_step|rocket|rocket32|rocket_noproj|soc [reps] [B]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -20,7 +20,17 @@ elif what == "pp_step":
     im = P.make_im("planar_push", lib, dev)
     X, U = W.knots("planar_push", 65536, seed=1)
     fn = lambda: im.step_grad(Xd, Ud)
+elif what.startswith("rocket") or what == "soc":
+    dt = torch.float32 if what == "rocket32" else torch.float64
+    info = od.RocketInfo(od.rocket, 12.5, 0.05, dtype=dt, device=dev)
+    X, U = W.rocket_inputs(int(sys.argv[3]) if len(sys.argv) > 3 else 65536, seed=3)
+    if what == "soc":
+        fn = lambda: info.project(Ud, grads=True)
+    else:
+        fn = lambda: info.solve(Xd, Ud, project=what != "rocket_noproj", grads=True)
 Xd, Ud = torch.tensor(X, device=dev), torch.tensor(U, device=dev)
+if what == "rocket32":
+    Xd, Ud = Xd.float(), Ud.float()
 for _ in range(reps):
     fn()
 torch.cuda.synchronize()
