@@ -688,9 +688,11 @@ OD_HD bool coop_iteration(const CoopLanes<CM, RO>& L, const Opts<double>& o, con
   // then -- a solve that jams spends most of its time here, ~8 trials in each of its 100 iterations -- the 16 lanes of the
   // row each try a step size (coop_trials_lanes), agree on the first accepted one (the one the sequential loop would
   // find) and the row re-evaluates that one in its cooperative form: same iterates, bit for bit
-  Vec zc = z;
-  Res rc = r;
-  double r_c = r_vio, k_c = k_vio;
+  // (at least one trial is evaluated -- max_ls >= 1 is enforced at the API --, so the candidates start out unset: initialising
+  // them from z / r costs 16 register moves per iteration that nothing reads)
+  Vec zc;
+  Res rc;
+  double r_c, k_c;
   auto trial = [&](double a) {
 #pragma unroll
     for (int k = 0; k < NQ; ++k) zc.q[k] = z.q[k] - a * D.q[k];

@@ -751,9 +751,9 @@ OD_HD bool c3_iteration(const C3Lanes<CM, RO>& L, const Opts<double>& o, const d
   // rounds of od_coop.h::coop_iteration exist here too (OD_EXPERIMENT_C3_PARALLEL_LS: the 8 lanes of the group each try a
   // step size, c3_trials_lanes): bit-identical results (profiles/r3_hash_c3_parallel_ls.json), planar push unchanged,
   // hopper rollouts 8 % (8192) to 48 % (>= 16 384, spills at two wavefronts per SIMD) slower -- profiles/r3_c3_parallel_ls_ab.json
-  Vec zc = z;
-  Res rc = r;
-  double r_c = r_vio, k_c = k_vio;
+  Vec zc;                                    // (set by the first trial: max_ls >= 1 is enforced at the API)
+  Res rc;
+  double r_c, k_c;
   auto trial = [&](double a) {
 #pragma unroll
     for (int k = 0; k < NQ; ++k) zc.q[k] = z.q[k] - a * D.q[k];

@@ -30,6 +30,29 @@ OD_HD double od_fma(double a, double b, double c) {
 #endif
 }
 
+// a * b + c with c a polynomial coefficient: the three-operand instruction, stated.  Left to itself hipcc 7.2 keeps the
+// coefficients in registers across the solve loop and evaluates a Horner step as a copy of the coefficient plus the two-operand
+// v_fmac_f64 -- two issue slots where one does (the 10 steps of od_sincos are on every line-search trial).  Same rounding.
+OD_HD double od_fma_coef(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+#else
+  return std::fma(a, b, c);
+#endif
+}
+// (the first step: both coefficients are constants, the multiplier comes from a scalar register)
+OD_HD double od_fma_coef2(double a, double kb, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(kb), "v"(c));
+  return d;
+#else
+  return std::fma(a, kb, c);
+#endif
+}
+
 // sin and cos of a joint angle.  The library routines carry a Payne-Hanek path for huge arguments
 // and cost ~200 instructions each on gfx950; angles on this path are O(1..1e3) rad, so: three-term
 // Cody-Waite reduction by pi/2 with FMAs (the reduced argument is good to ~1 ulp for |x| < 2^30 and
@@ -43,18 +66,18 @@ OD_HD void od_sincos(double x, double& sn, double& cs) {
   r = od_fma(n, 1.4973849048591698e-33, r);                // and the next
   const double z = r * r;
   // sin(r) = r + r^3 (S1 + z S2 + ... + z^5 S6)
-  double ps = od_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  ps = od_fma(z, ps, 2.75573137070700676789e-06);
-  ps = od_fma(z, ps, -1.98412698298579493134e-04);
-  ps = od_fma(z, ps, 8.33333333332248946124e-03);
-  ps = od_fma(z, ps, -1.66666666666666324348e-01);
+  double ps = od_fma_coef2(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = od_fma_coef(z, ps, 2.75573137070700676789e-06);
+  ps = od_fma_coef(z, ps, -1.98412698298579493134e-04);
+  ps = od_fma_coef(z, ps, 8.33333333332248946124e-03);
+  ps = od_fma_coef(z, ps, -1.66666666666666324348e-01);
   const double s = od_fma(z * r, ps, r);
   // cos(r) = 1 - z/2 + z^2 (C1 + z C2 + ... + z^5 C6), summed so that the rounding of 1 - z/2 is recovered
-  double pc = od_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  pc = od_fma(z, pc, -2.75573143513906633035e-07);
-  pc = od_fma(z, pc, 2.48015872894767294178e-05);
-  pc = od_fma(z, pc, -1.38888888888741095749e-03);
-  pc = od_fma(z, pc, 4.16666666666666019037e-02);
+  double pc = od_fma_coef2(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = od_fma_coef(z, pc, -2.75573143513906633035e-07);
+  pc = od_fma_coef(z, pc, 2.48015872894767294178e-05);
+  pc = od_fma_coef(z, pc, -1.38888888888741095749e-03);
+  pc = od_fma_coef(z, pc, 4.16666666666666019037e-02);
   const double hz = 0.5 * z, w = 1.0 - hz;
   const double c = w + (((1.0 - w) - hz) + z * z * pc);
   const int q = (int)n;                                    // quadrant (saturates, harmlessly, for |x| > 3e9)
