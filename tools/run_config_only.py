@@ -5,7 +5,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import workloads as W, parity_checks as P
 import optimization_dynamics_amd as od
-lib = od.default_library(); dev = "cuda:0"
+from optimization_dynamics_amd import _lib as _L
+lib = _L.Library(os.environ["OD_LIB"]) if os.environ.get("OD_LIB") else od.default_library()   # (OD_LIB: a variant build)
+dev = "cuda:0"
 what = sys.argv[1]; reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 if what == "bundle":
     im = P.make_im("planar_push", lib, dev)
@@ -22,7 +24,7 @@ elif what == "pp_step":
     fn = lambda: im.step_grad(Xd, Ud)
 elif what.startswith("rocket") or what == "soc":
     dt = torch.float32 if what == "rocket32" else torch.float64
-    info = od.RocketInfo(od.rocket, 12.5, 0.05, dtype=dt, device=dev)
+    info = od.RocketInfo(od.rocket, 12.5, 0.05, dtype=dt, device=dev, lib=lib)
     X, U = W.rocket_inputs(int(sys.argv[3]) if len(sys.argv) > 3 else 65536, seed=3)
     if what == "soc":
         fn = lambda: info.project(Ud, grads=True)
@@ -34,3 +36,9 @@ if what == "rocket32":
 for _ in range(reps):
     fn()
 torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for _ in range(20):
+    fn()
+torch.cuda.synchronize()
+print("%s: %.4f ms per call" % (what, (time.perf_counter() - t0) / 20 * 1e3))

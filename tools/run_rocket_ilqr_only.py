@@ -5,7 +5,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import ilqr_checks as C
 import optimization_dynamics_amd as od
-lib = od.default_library()
+from optimization_dynamics_amd import _lib as _L
+lib = _L.Library(os.environ["OD_LIB"]) if os.environ.get("OD_LIB") else od.default_library()   # (OD_LIB: a variant build)
 dtype = torch.float64 if (len(sys.argv) > 2 and sys.argv[2] == "f64") else torch.float32
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dyn, obj, x1, U0 = C.rocket_problem(lib, "cuda:0", B, 60, dtype=dtype, seed=1)
