@@ -327,11 +327,13 @@ __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward(IlqrArgs a) {
 // trajectories: 2.54 ms per call, 35 % of an iLQR iteration of BASELINE config 5).  Here thread (s, j) = (tid / TB, tid % TB)
 // works on trajectory b0 + j, so the TB threads of a slot read one full segment; every matrix lives in LDS as [entry][j];
 // the entries of an operation are dealt to the 256 / TB slots.  Same sums in the same order as above: same results.
-template <int TB>
+// (N, M: the sizes as compile-time constants for the models in use -- entry -> (row, column) becomes shifts and multiplies instead
+// of integer divisions and the inner products unroll; 0, 0: any size)
+template <int TB, int N = 0, int M = 0>
 __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward_tb(IlqrArgs a) {
   extern __shared__ double od_il_lds[];
   constexpr int NS = OD_IL_THREADS / TB;
-  const int n = a.n, m = a.m, tid = threadIdx.x, j = tid % TB, s = tid / TB;
+  const int n = N ? N : a.n, m = N ? M : a.m, tid = threadIdx.x, j = tid % TB, s = tid / TB;
   const int nn = n * n, nm = n * m, mm = m * m;
   const long b = (long)blockIdx.x * TB + j;
   const bool live = b < a.B;
@@ -1053,10 +1055,21 @@ int od_ilqr_backward(od_handle h, long B, int T, int n, int m, const void* A, co
     // 1024 trajectories 4.30 (one) / 4.53 (two) / 5.02 (eight))
     int tb = (L != OD_LAYOUT_BATCH_MINOR) ? 1 : (8 * per <= 65536 ? 8 : (4 * per <= 65536 ? 4 : (2 * per <= 65536 ? 2 : 1)));
     while (tb > 1 && B / tb < 1024) tb >>= 1;
-    if (tb == 8) hipLaunchKernelGGL((k_ilqr_backward_tb<8>), od_grid(B, 8), dim3(OD_IL_THREADS), 8 * per, h->stream, a);
-    else if (tb == 4) hipLaunchKernelGGL((k_ilqr_backward_tb<4>), od_grid(B, 4), dim3(OD_IL_THREADS), 4 * per, h->stream, a);
-    else if (tb == 2) hipLaunchKernelGGL((k_ilqr_backward_tb<2>), od_grid(B, 2), dim3(OD_IL_THREADS), 2 * per, h->stream, a);
+#define OD_IL_LAUNCH(TB_, N_, M_) hipLaunchKernelGGL((k_ilqr_backward_tb<TB_, N_, M_>), od_grid(B, TB_), dim3(OD_IL_THREADS), TB_ * per, h->stream, a)
+#define OD_IL_SIZES(TB_)                                                                                              \
+  do {                                                                                                                \
+    if (n == 12 && m == 3) OD_IL_LAUNCH(TB_, 12, 3);      /* rocket */                                                \
+    else if (n == 8 && m == 2) OD_IL_LAUNCH(TB_, 8, 2);   /* hopper */                                                \
+    else if (n == 4 && m == 1) OD_IL_LAUNCH(TB_, 4, 1);   /* acrobot, cartpole */                                     \
+    else if (n == 10 && m == 2) OD_IL_LAUNCH(TB_, 10, 2); /* planar push */                                           \
+    else OD_IL_LAUNCH(TB_, 0, 0);                                                                                     \
+  } while (0)
+    if (tb == 8) OD_IL_SIZES(8);
+    else if (tb == 4) OD_IL_SIZES(4);
+    else if (tb == 2) OD_IL_SIZES(2);
     else hipLaunchKernelGGL(k_ilqr_backward, dim3((unsigned)B), dim3(OD_IL_THREADS), 0, h->stream, a);
+#undef OD_IL_SIZES
+#undef OD_IL_LAUNCH
   }
 #else
   hipLaunchKernelGGL(k_ilqr_backward_serial, od_grid(B, OD_BLOCK), dim3(OD_BLOCK), 0, h->stream, a);
