@@ -79,6 +79,46 @@ def check_backward_trajectories_per_workgroup(lib, device, sizes=(2304, 4608, 90
             assert torch.equal(Ks, K[..., sl]) and torch.equal(ks, k[..., sl]) and torch.equal(dVs, dV[:, sl]) and torch.equal(bs, bst[sl]), (B, b0)
 
 
+def check_backward_sizes(lib, device, sizes=((12, 3), (8, 2), (4, 1), (10, 2), (6, 2), (16, 12)), batches=(5, 2304, 4608), T=5):
+    """od_ilqr_backward on random well-posed data through the C ABI, every (n, m) instantiation of k_ilqr_backward_tb (the five models'
+    sizes are template parameters, anything else takes the run-time form) at 1 / 2 / 4 trajectories per workgroup, against the numpy
+    Riccati recursion (oracle/ilqr_np.py) on a sample of trajectories; ragged last workgroup included"""
+    from oracle import ilqr_np
+    from optimization_dynamics_amd.dynamics import _ptr
+    im = P_make_im(lib, device)
+    for n, m in sizes:
+        for B in batches:
+            rng = np.random.default_rng(1000 * n + m + B)
+            A = np.eye(n)[:, :, None, None] + 0.1 * rng.normal(size=(n, n, T, B))
+            Bm = rng.normal(size=(n, m, T, B))
+            def spd(k, shape):
+                G = rng.normal(size=(k, k) + shape)
+                return np.einsum("ij...,kj...->ik...", G, G) + np.eye(k).reshape((k, k) + (1,) * len(shape))
+            lxx, luu, Vxx = spd(n, (T, B)), spd(m, (T, B)), spd(n, (B,))
+            lux = 0.1 * rng.normal(size=(m, n, T, B)); lx = rng.normal(size=(n, T, B)); lu = rng.normal(size=(m, T, B)); Vx = rng.normal(size=(n, B))
+            col = lambda M: torch.tensor(np.ascontiguousarray(M.transpose((1, 0) + tuple(range(2, M.ndim))).reshape((-1,) + M.shape[2:])), device=device)
+            dev = lambda M: torch.tensor(np.ascontiguousarray(M), device=device)
+            K = torch.empty(m * n, T, B, dtype=torch.float64, device=device); k = torch.empty(m, T, B, dtype=torch.float64, device=device)
+            dV = torch.empty(2, B, dtype=torch.float64, device=device); st = torch.empty(B, dtype=torch.int32, device=device)
+            args = [col(A), col(Bm), col(lxx), col(luu), col(lux), dev(lx), dev(lu), col(Vxx), dev(Vx)]
+            im._use_current_stream()
+            lib.check(lib.cdll.od_ilqr_backward(im._h, B, T, n, m, *[_ptr(a) for a in args], 1e-6, _ptr(K), _ptr(k), _ptr(dV), _ptr(st)))
+            assert (st == 1).all(), (n, m, B)
+            Kh, kh, dVh = K.cpu().numpy(), k.cpu().numpy(), dV.cpu().numpy()
+            for b in sorted({0, 1, B // 2, B - 2, B - 1}):
+                mv = lambda M: np.moveaxis(M[..., b], -1, 0)        # (r, c, T) -> (T, r, c)
+                Ko, ko, dVo = ilqr_np.backward(mv(A), mv(Bm), mv(lxx), mv(luu), mv(lux), lx[:, :, b].T, lu[:, :, b].T, Vxx[:, :, b], Vx[:, b], 1e-6)
+                Kd = Kh[:, :, b].reshape(n, m, T).transpose(2, 1, 0)   # stored col-major m x n per knot
+                sc = max(1.0, np.abs(Ko).max())
+                assert np.abs(Kd - Ko).max() < 1e-8 * sc and np.abs(kh[:, :, b].T - ko).max() < 1e-8 * sc, (n, m, B, b)
+                assert np.abs(dVh[:, b] - dVo).max() < 1e-8 * max(1.0, np.abs(dVo).max())
+
+
+def P_make_im(lib, device):
+    import parity_checks as P
+    return P.make_im("cartpole_friction", lib, device)
+
+
 def check_solver_decreases_cost(lib, device, B=8, T=25):
     im, obj, x1, U0 = cartpole_problem(lib, device, B, T, seed=1)
     solver = IL.ILQR(im, obj, T)

@@ -24,6 +24,15 @@ def test_one_bad_trajectory_does_not_hurt_the_batch_gpu(gpu_lib):
 
 
 @pytest.mark.gpu
+def test_backward_every_size_instantiation_gpu(gpu_lib):
+    C.check_backward_sizes(gpu_lib, "cuda:0")
+
+
+def test_backward_sizes_cpu(emu_lib):
+    C.check_backward_sizes(emu_lib, "cpu", sizes=((12, 3), (6, 2)), batches=(5,), T=4)
+
+
+@pytest.mark.gpu
 def test_backward_trajectories_per_workgroup_gpu(gpu_lib):
     C.check_backward_trajectories_per_workgroup(gpu_lib, "cuda:0")
 
