@@ -458,7 +458,9 @@ def rocket_projection() -> ModelSpec:
         z_init=[0.1, 0.1, 1.1, 0.1, 0.1, 0.1, 0.0, 0.1, 0.1, 1.1],
         kind="proj", idx_zq=[0, 1, 2],
         # pivots: row3 (uu-u3-s) on s=z4 [coef -1]; row4 (-y-w) on w=z5 [-1]; rows0,1 on v1,v2 (z7,z8) [-1];
-        # row2 on v3 (z9) [-1]; remaining handled by the runtime-pivoted dense tail
+        # row2 on v3 (z9) [-1]; remaining handled by the runtime-pivoted dense tail.  (Tried in round 3: two more static pivots, the
+        # slack s for row5 and u3 for row6, leaving a 3 x 3 tail.  With eps_min = 0 the step goes all the way to the boundary
+        # (tau = 1), s or u3 become exactly 0 on some solves and the static pivot divides by it -- the pivoted 5 x 5 survives that.)
         elim=[(3, 4), (4, 5), (0, 7), (1, 8), (2, 9)],
         # dynamics.jl:77-86
         opts=dict(r_tol=1e-8, kappa_tol=1e-4, max_iter=100, max_ls=25, eps_min=0.0,
