@@ -144,9 +144,13 @@ OD_HD int coop_copy(int) { return 0; }
 #endif
 
 template <class M> constexpr bool soc_uniform() {
-  for (int c = 0; c < M::NSOC; ++c)
-    if (M::SOCOFF[c + 1] - M::SOCOFF[c] != M::SOCOFF[1] - M::SOCOFF[0]) return false;
-  return M::NSOC > 0;
+  if constexpr (M::NSOC > 0) {          // (SOCOFF has NSOC + 1 entries; a model without cones has a one-entry placeholder)
+    for (int c = 0; c < M::NSOC; ++c)
+      if (M::SOCOFF[c + 1] - M::SOCOFF[c] != M::SOCOFF[1] - M::SOCOFF[0]) return false;
+    return true;
+  } else {
+    return false;
+  }
 }
 template <class T> OD_HD T coop_pick(int g, T v0, T v1, T v2, T v3) {
   const T lo = (g & 1) ? v1 : v0, hi = (g & 1) ? v3 : v2;
