@@ -95,7 +95,8 @@ int od_set_launch_config(od_handle h, int ppw, int waves_per_block);
  * the critical path of a problem.  mode 0 = automatic (per model and batch size), 1 = never (lane-per-problem kernels),
  * 2 = always where the model has them (the 16-lane form where it has both), 3 = always, the 8-lane form first.
  * Results agree with the lane-per-problem kernels to rounding; which kernel the automatic mode picks depends on the batch
- * size, so pin a mode where results must not depend on it at rounding level. */
+ * size, so pin a mode where results must not depend on it at rounding level.  od_ilqr_backward follows the same switch: mode 1
+ * keeps its workgroup (LDS) kernels, any other mode takes the one-trajectory-per-16-lanes kernel where it exists (m <= 4). */
 int od_set_cooperative(od_handle h, int mode);
 /* diagnostics: the iterate at which the last od_step_grad* / od_rollout* call on this handle differentiated each of its
  * K knots -- z at the first iterate satisfying (r_tol, kappa_grad) and, in row nz, the clamp of the orthant variables

@@ -426,6 +426,545 @@ __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward_tb(IlqrArgs a) 
   }
 #undef OD_E
 }
+// ONE TRAJECTORY PER 16-LANE DPP ROW (round 3; batch-minor data, m <= 4).  Lane i of the row keeps ROW i of every n-column
+// matrix in registers (Vxx, A, A', W = Vxx A, Qxx, the new Vxx) and row i of the m-column ones (B, W B, Qux', K'); an inner product
+// over the rows of another matrix reads them from their lanes with `v_fmac_f64_dpp row_newbcast` -- the instruction of the
+// cooperative solve kernels (od_coop.h) -- four to an asm block behind one `s_nop 1` (the DPP read-after-write hazard is not
+// interlocked on gfx950).  The m x m block (Quu, its Cholesky factor, k) is replicated in every lane.  No LDS traffic except the
+// transpose for the symmetrisation of Vxx, no workgroup barrier inside a knot but that one; 16 trajectories per workgroup, four
+// per wavefront: 4096 trajectories are 1024 wavefronts, one per SIMD.  Sums run over the same terms as the kernels above in the
+// same order, fused (fmac) where those round the product first: results agree to rounding, not bit for bit.
+// acc[c] += sum_{l = L0 .. L0 + LW - 1} (y[c] of lane l) * x[l]  for c = 0 .. CW - 1: one asm block, the CW accumulators interleaved
+// (a chain of dependent v_fmac_f64_dpp on ONE accumulator issues at a quarter of the rate; the compiler cannot interleave
+// separate asm blocks)
+template <int CW, int LW, int L0> __device__ __forceinline__ void od_row_block(double* acc, const double* y, const double* x) {
+  if constexpr (CW == 4 && LW == 4) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %4, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %5, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %6, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %7, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %4, %9 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %5, %9 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %6, %9 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %7, %9 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %4, %10 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %5, %10 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %6, %10 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %7, %10 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %4, %11 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %5, %11 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %6, %11 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %7, %11 row_newbcast:%15 row_mask:0xf bank_mask:0xf"
+          : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(x[L0 + 0]), "v"(x[L0 + 1]), "v"(x[L0 + 2]), "v"(x[L0 + 3]), "n"(L0 + 0), "n"(L0 + 1), "n"(L0 + 2), "n"(L0 + 3));
+  }   else if constexpr (CW == 4 && LW == 2) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %4, %8 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %5, %8 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %6, %8 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %7, %8 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %4, %9 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %5, %9 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %6, %9 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %7, %9 row_newbcast:%11 row_mask:0xf bank_mask:0xf"
+          : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(x[L0 + 0]), "v"(x[L0 + 1]), "n"(L0 + 0), "n"(L0 + 1));
+  }   else if constexpr (CW == 4 && LW == 1) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %5, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %6, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+          : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(x[L0 + 0]), "n"(L0 + 0));
+  }   else if constexpr (CW == 3 && LW == 4) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %3, %6 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %5, %6 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %3, %7 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %4, %7 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %5, %7 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %3, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %4, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %5, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %3, %9 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %4, %9 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %5, %9 row_newbcast:%13 row_mask:0xf bank_mask:0xf"
+          : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(x[L0 + 0]), "v"(x[L0 + 1]), "v"(x[L0 + 2]), "v"(x[L0 + 3]), "n"(L0 + 0), "n"(L0 + 1), "n"(L0 + 2), "n"(L0 + 3));
+  }   else if constexpr (CW == 3 && LW == 2) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %3, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %5, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %3, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %4, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %5, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+          : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(x[L0 + 0]), "v"(x[L0 + 1]), "n"(L0 + 0), "n"(L0 + 1));
+  }   else if constexpr (CW == 3 && LW == 1) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %3, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %5, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+          : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(x[L0 + 0]), "n"(L0 + 0));
+  }   else if constexpr (CW == 2 && LW == 4) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %2, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %3, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %2, %6 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %3, %6 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %2, %7 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %3, %7 row_newbcast:%11 row_mask:0xf bank_mask:0xf"
+          : "+v"(acc[0]), "+v"(acc[1]) : "v"(y[0]), "v"(y[1]), "v"(x[L0 + 0]), "v"(x[L0 + 1]), "v"(x[L0 + 2]), "v"(x[L0 + 3]), "n"(L0 + 0), "n"(L0 + 1), "n"(L0 + 2), "n"(L0 + 3));
+  }   else if constexpr (CW == 2 && LW == 2) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %2, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %3, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+          : "+v"(acc[0]), "+v"(acc[1]) : "v"(y[0]), "v"(y[1]), "v"(x[L0 + 0]), "v"(x[L0 + 1]), "n"(L0 + 0), "n"(L0 + 1));
+  }   else if constexpr (CW == 2 && LW == 1) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+          : "+v"(acc[0]), "+v"(acc[1]) : "v"(y[0]), "v"(y[1]), "v"(x[L0 + 0]), "n"(L0 + 0));
+  }   else if constexpr (CW == 1 && LW == 4) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %1, %3 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %1, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %1, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+          : "+v"(acc[0]) : "v"(y[0]), "v"(x[L0 + 0]), "v"(x[L0 + 1]), "v"(x[L0 + 2]), "v"(x[L0 + 3]), "n"(L0 + 0), "n"(L0 + 1), "n"(L0 + 2), "n"(L0 + 3));
+  }   else if constexpr (CW == 1 && LW == 2) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %1, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+          : "+v"(acc[0]) : "v"(y[0]), "v"(x[L0 + 0]), "v"(x[L0 + 1]), "n"(L0 + 0), "n"(L0 + 1));
+  }   else if constexpr (CW == 1 && LW == 1) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+          : "+v"(acc[0]) : "v"(y[0]), "v"(x[L0 + 0]), "n"(L0 + 0));
+  }
+}
+// acc[0 .. NC-1] += sum_{l < NL} (y[c] of lane l) * x[l]
+template <int NC, int NL, int C0 = 0, int L0 = 0> __device__ __forceinline__ void od_row_mac(double* acc, const double* y, const double* x) {
+  if constexpr (C0 < NC) {
+    constexpr int CW = (NC - C0) >= 4 ? 4 : (NC - C0);
+    if constexpr (L0 < NL) {
+      constexpr int LW = (NL - L0) >= 4 ? 4 : ((NL - L0) >= 2 ? 2 : 1);
+      od_row_block<CW, LW, L0>(acc + C0, y + C0, x);
+      od_row_mac<NC, NL, C0, L0 + LW>(acc, y, x);
+    } else {
+      od_row_mac<NC, NL, C0 + CW, 0>(acc, y, x);
+    }
+  }
+}
+template <int L> __device__ __forceinline__ double od_row_bc(double x) {
+  double r;
+  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(L));
+  return r;
+}
+template <int C0, int N, int M> __device__ __forceinline__ void od_row_vxx_terms(double* Wn, const double* G, const double* KT, const double* QuxT) {
+  // Wn[c] += sum_j K'[i][j] (G[j] of lane c) + Qux'[i][j] (K'[j] of lane c),  c = C0 .. N - 1; four columns to an asm block
+  if constexpr (C0 < N) {
+    constexpr int CW = (N - C0) >= 4 ? 4 : (N - C0);
+    static_assert(M >= 1 && M <= 4, "");
+    if constexpr (CW == 4 && M == 1) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %4, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %4, %5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %4, %5 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %5, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %5, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %5, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %5, %6 row_newbcast:%10 row_mask:0xf bank_mask:0xf"
+          : "+v"(Wn[C0 + 0]), "+v"(Wn[C0 + 1]), "+v"(Wn[C0 + 2]), "+v"(Wn[C0 + 3]) : "v"(G[0]), "v"(KT[0]), "v"(QuxT[0]), "n"(C0 + 0), "n"(C0 + 1), "n"(C0 + 2), "n"(C0 + 3));
+    }     else if constexpr (CW == 4 && M == 2) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %4, %6 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %4, %6 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %4, %6 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %6, %8 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %6, %8 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %6, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %6, %8 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %5, %7 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %5, %7 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %5, %7 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %5, %7 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %7, %9 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %7, %9 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %7, %9 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %7, %9 row_newbcast:%13 row_mask:0xf bank_mask:0xf"
+          : "+v"(Wn[C0 + 0]), "+v"(Wn[C0 + 1]), "+v"(Wn[C0 + 2]), "+v"(Wn[C0 + 3]) : "v"(G[0]), "v"(G[1]), "v"(KT[0]), "v"(KT[1]), "v"(QuxT[0]), "v"(QuxT[1]), "n"(C0 + 0), "n"(C0 + 1), "n"(C0 + 2), "n"(C0 + 3));
+    }     else if constexpr (CW == 4 && M == 3) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %4, %7 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %4, %7 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %4, %7 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %4, %7 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %7, %10 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %7, %10 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %7, %10 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %7, %10 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %5, %8 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %5, %8 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %5, %8 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %5, %8 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %8, %11 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %8, %11 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %8, %11 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %8, %11 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %6, %9 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %6, %9 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %6, %9 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %6, %9 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %9, %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %9, %12 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %9, %12 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %9, %12 row_newbcast:%16 row_mask:0xf bank_mask:0xf"
+          : "+v"(Wn[C0 + 0]), "+v"(Wn[C0 + 1]), "+v"(Wn[C0 + 2]), "+v"(Wn[C0 + 3]) : "v"(G[0]), "v"(G[1]), "v"(G[2]), "v"(KT[0]), "v"(KT[1]), "v"(KT[2]), "v"(QuxT[0]), "v"(QuxT[1]), "v"(QuxT[2]), "n"(C0 + 0), "n"(C0 + 1), "n"(C0 + 2), "n"(C0 + 3));
+    }     else if constexpr (CW == 4 && M == 4) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %4, %8 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %4, %8 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %4, %8 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %4, %8 row_newbcast:%19 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %8, %12 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %8, %12 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %8, %12 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %8, %12 row_newbcast:%19 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %5, %9 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %5, %9 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %5, %9 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %5, %9 row_newbcast:%19 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %9, %13 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %9, %13 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %9, %13 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %9, %13 row_newbcast:%19 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %6, %10 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %6, %10 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %6, %10 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %6, %10 row_newbcast:%19 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %10, %14 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %10, %14 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %10, %14 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %10, %14 row_newbcast:%19 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %7, %11 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %7, %11 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %7, %11 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %7, %11 row_newbcast:%19 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %11, %15 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %11, %15 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %11, %15 row_newbcast:%18 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %3, %11, %15 row_newbcast:%19 row_mask:0xf bank_mask:0xf"
+          : "+v"(Wn[C0 + 0]), "+v"(Wn[C0 + 1]), "+v"(Wn[C0 + 2]), "+v"(Wn[C0 + 3]) : "v"(G[0]), "v"(G[1]), "v"(G[2]), "v"(G[3]), "v"(KT[0]), "v"(KT[1]), "v"(KT[2]), "v"(KT[3]), "v"(QuxT[0]), "v"(QuxT[1]), "v"(QuxT[2]), "v"(QuxT[3]), "n"(C0 + 0), "n"(C0 + 1), "n"(C0 + 2), "n"(C0 + 3));
+    }     else if constexpr (CW == 3 && M == 1) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %3, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %3, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %4, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %4, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %4, %5 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
+          : "+v"(Wn[C0 + 0]), "+v"(Wn[C0 + 1]), "+v"(Wn[C0 + 2]) : "v"(G[0]), "v"(KT[0]), "v"(QuxT[0]), "n"(C0 + 0), "n"(C0 + 1), "n"(C0 + 2));
+    }     else if constexpr (CW == 3 && M == 2) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %3, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %3, %5 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %3, %5 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %5, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %5, %7 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %5, %7 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %4, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %4, %6 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %6, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %6, %8 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %6, %8 row_newbcast:%11 row_mask:0xf bank_mask:0xf"
+          : "+v"(Wn[C0 + 0]), "+v"(Wn[C0 + 1]), "+v"(Wn[C0 + 2]) : "v"(G[0]), "v"(G[1]), "v"(KT[0]), "v"(KT[1]), "v"(QuxT[0]), "v"(QuxT[1]), "n"(C0 + 0), "n"(C0 + 1), "n"(C0 + 2));
+    }     else if constexpr (CW == 3 && M == 3) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %3, %6 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %3, %6 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %3, %6 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %6, %9 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %6, %9 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %6, %9 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %4, %7 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %4, %7 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %4, %7 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %7, %10 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %7, %10 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %7, %10 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %5, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %5, %8 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %5, %8 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %8, %11 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %8, %11 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %8, %11 row_newbcast:%14 row_mask:0xf bank_mask:0xf"
+          : "+v"(Wn[C0 + 0]), "+v"(Wn[C0 + 1]), "+v"(Wn[C0 + 2]) : "v"(G[0]), "v"(G[1]), "v"(G[2]), "v"(KT[0]), "v"(KT[1]), "v"(KT[2]), "v"(QuxT[0]), "v"(QuxT[1]), "v"(QuxT[2]), "n"(C0 + 0), "n"(C0 + 1), "n"(C0 + 2));
+    }     else if constexpr (CW == 3 && M == 4) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %3, %7 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %3, %7 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %3, %7 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %7, %11 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %7, %11 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %7, %11 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %4, %8 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %4, %8 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %4, %8 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %8, %12 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %8, %12 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %8, %12 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %5, %9 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %5, %9 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %5, %9 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %9, %13 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %9, %13 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %9, %13 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %6, %10 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %6, %10 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %6, %10 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %10, %14 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %10, %14 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %2, %10, %14 row_newbcast:%17 row_mask:0xf bank_mask:0xf"
+          : "+v"(Wn[C0 + 0]), "+v"(Wn[C0 + 1]), "+v"(Wn[C0 + 2]) : "v"(G[0]), "v"(G[1]), "v"(G[2]), "v"(G[3]), "v"(KT[0]), "v"(KT[1]), "v"(KT[2]), "v"(KT[3]), "v"(QuxT[0]), "v"(QuxT[1]), "v"(QuxT[2]), "v"(QuxT[3]), "n"(C0 + 0), "n"(C0 + 1), "n"(C0 + 2));
+    }     else if constexpr (CW == 2 && M == 1) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %2, %3 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+          : "+v"(Wn[C0 + 0]), "+v"(Wn[C0 + 1]) : "v"(G[0]), "v"(KT[0]), "v"(QuxT[0]), "n"(C0 + 0), "n"(C0 + 1));
+    }     else if constexpr (CW == 2 && M == 2) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %2, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %4, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %3, %5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %3, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %5, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %5, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+          : "+v"(Wn[C0 + 0]), "+v"(Wn[C0 + 1]) : "v"(G[0]), "v"(G[1]), "v"(KT[0]), "v"(KT[1]), "v"(QuxT[0]), "v"(QuxT[1]), "n"(C0 + 0), "n"(C0 + 1));
+    }     else if constexpr (CW == 2 && M == 3) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %2, %5 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %5, %8 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %5, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %3, %6 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %3, %6 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %6, %9 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %6, %9 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %4, %7 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %4, %7 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %7, %10 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %7, %10 row_newbcast:%12 row_mask:0xf bank_mask:0xf"
+          : "+v"(Wn[C0 + 0]), "+v"(Wn[C0 + 1]) : "v"(G[0]), "v"(G[1]), "v"(G[2]), "v"(KT[0]), "v"(KT[1]), "v"(KT[2]), "v"(QuxT[0]), "v"(QuxT[1]), "v"(QuxT[2]), "n"(C0 + 0), "n"(C0 + 1));
+    }     else if constexpr (CW == 2 && M == 4) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %2, %6 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %2, %6 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %6, %10 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %6, %10 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %3, %7 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %3, %7 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %7, %11 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %7, %11 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %4, %8 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %4, %8 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %8, %12 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %8, %12 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %5, %9 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %5, %9 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %9, %13 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %1, %9, %13 row_newbcast:%15 row_mask:0xf bank_mask:0xf"
+          : "+v"(Wn[C0 + 0]), "+v"(Wn[C0 + 1]) : "v"(G[0]), "v"(G[1]), "v"(G[2]), "v"(G[3]), "v"(KT[0]), "v"(KT[1]), "v"(KT[2]), "v"(KT[3]), "v"(QuxT[0]), "v"(QuxT[1]), "v"(QuxT[2]), "v"(QuxT[3]), "n"(C0 + 0), "n"(C0 + 1));
+    }     else if constexpr (CW == 1 && M == 1) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+          : "+v"(Wn[C0 + 0]) : "v"(G[0]), "v"(KT[0]), "v"(QuxT[0]), "n"(C0 + 0));
+    }     else if constexpr (CW == 1 && M == 2) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %1, %3 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %3, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %2, %4 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %4, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+          : "+v"(Wn[C0 + 0]) : "v"(G[0]), "v"(G[1]), "v"(KT[0]), "v"(KT[1]), "v"(QuxT[0]), "v"(QuxT[1]), "n"(C0 + 0));
+    }     else if constexpr (CW == 1 && M == 3) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %1, %4 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %4, %7 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %5, %8 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %3, %6 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %6, %9 row_newbcast:%10 row_mask:0xf bank_mask:0xf"
+          : "+v"(Wn[C0 + 0]) : "v"(G[0]), "v"(G[1]), "v"(G[2]), "v"(KT[0]), "v"(KT[1]), "v"(KT[2]), "v"(QuxT[0]), "v"(QuxT[1]), "v"(QuxT[2]), "n"(C0 + 0));
+    }     else if constexpr (CW == 1 && M == 4) {
+      asm("s_nop 1\n\t"
+          "v_fmac_f64_dpp %0, %1, %5 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %5, %9 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %2, %6 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %6, %10 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %3, %7 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %7, %11 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %4, %8 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f64_dpp %0, %8, %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf"
+          : "+v"(Wn[C0 + 0]) : "v"(G[0]), "v"(G[1]), "v"(G[2]), "v"(G[3]), "v"(KT[0]), "v"(KT[1]), "v"(KT[2]), "v"(KT[3]), "v"(QuxT[0]), "v"(QuxT[1]), "v"(QuxT[2]), "v"(QuxT[3]), "n"(C0 + 0));
+    }
+    od_row_vxx_terms<C0 + CW, N, M>(Wn, G, KT, QuxT);
+  }
+}
+template <int A_, int M> __device__ __forceinline__ void od_row_replicate(const double* row, double (*R)[M]) {
+  // R[a][j] = (row[j] of lane a): the m x m block that lanes 0 .. m-1 hold by rows, in every lane
+  if constexpr (A_ < M) {
+#pragma unroll
+    for (int j = 0; j < M; ++j) R[A_][j] = od_row_bc<A_>(row[j]);
+    od_row_replicate<A_ + 1, M>(row, R);
+  }
+}
+template <int A_, int M> __device__ __forceinline__ void od_row_replicate1(double v, double* R) {
+  if constexpr (A_ < M) { R[A_] = od_row_bc<A_>(v); od_row_replicate1<A_ + 1, M>(v, R); }
+}
+
+constexpr int OD_IL_ROW_PAD = 17;     // doubles per row of the transpose pad (16 + 1: the column reads hit 16 banks)
+template <int N, int M>
+__global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward_row(IlqrArgs a) {
+  static_assert(N <= 16 && M <= 4 && M <= N, "one matrix row per lane of a 16-lane DPP row; the m x m block is replicated");
+  __shared__ double pad[OD_IL_THREADS / 16][16 * OD_IL_ROW_PAD];
+  const int tid = threadIdx.x, i = tid & 15, rw = tid >> 4;
+  const long b = (long)blockIdx.x * (OD_IL_THREADS / 16) + rw;
+  const bool live = b < a.B;
+  const long bb = live ? b : a.B - 1;                 // (rows past the batch repeat its last trajectory, store nothing)
+  const int ir = i < N ? i : N - 1, im = i < M ? i : M - 1;       // (lanes without a row repeat the last one)
+  double Vr[N], vx, dV0 = 0.0, dV1 = 0.0;
+  int okf = 1;
+#pragma unroll
+  for (int c = 0; c < N; ++c) Vr[c] = a.VxxT.at(ir + N * c, bb);
+  vx = a.VxT.at(ir, bb);
+  // the rows of A and B, which the first products of a knot wait for, are requested one knot ahead.  (Requesting every operand a
+  // knot ahead was measured too: 64 trajectories 371 -> 325 us, but 4096 trajectories 439 -> 449 and 16 384 1.81 -> 1.93 ms -- the
+  // 96 extra registers end the second wavefront per SIMD, and from 4096 trajectories on the kernel is bound by its memory traffic.)
+  double Ar[N], Br[M], Ac[N], Bc[N], lxr[N], luxT[M], luur[M], lxv, luv;
+  auto request_a = [&](long kq) {      // what the first products need
+#pragma unroll
+    for (int c = 0; c < N; ++c) Ar[c] = a.A.at(ir + N * c, kq);
+#pragma unroll
+    for (int j = 0; j < M; ++j) Br[j] = a.Bm.at(ir + N * j, kq);
+  };
+  auto request_b = [&](long kq) {      // the transposes and the cost expansion
+#pragma unroll
+    for (int c = 0; c < N; ++c) { Ac[c] = a.A.at(c + N * ir, kq); lxr[c] = a.lxx.at(ir + N * c, kq); }
+#pragma unroll
+    for (int c = 0; c < N; ++c) Bc[c] = a.Bm.at(c + N * im, kq);
+#pragma unroll
+    for (int j = 0; j < M; ++j) { luxT[j] = a.lux.at(j + M * ir, kq); luur[j] = a.luu.at(im + M * j, kq); }
+    lxv = a.lx.at(ir, kq);
+    luv = a.lu.at(im, kq);
+  };
+  request_a((long)(a.T - 1) * a.B + bb);
+  for (int t = a.T - 1; t >= 0; --t) {
+    const long kk = (long)t * a.B + bb;
+    double W[N], WB[M], Qxx[N], QuxT[M], Quu[M], Qx, Qu;
+    request_b(kk);
+    // W = Vxx A, WB = Vxx B  (row i)
+#pragma unroll
+    for (int c = 0; c < N; ++c) W[c] = 0.0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) WB[j] = 0.0;
+    od_row_mac<N, N>(W, Ar, Vr);
+    od_row_mac<M, N>(WB, Br, Vr);
+    if (t > 0) request_a(kk - a.B);
+#pragma unroll
+    for (int c = 0; c < N; ++c) Qxx[c] = lxr[c];
+#pragma unroll
+    for (int j = 0; j < M; ++j) { QuxT[j] = luxT[j]; Quu[j] = luur[j]; }
+    Qx = lxv;
+    Qu = luv;
+    // Qxx = lxx + A'W, Qux' = lux' + A'(WB) (row i);  Quu = luu + B'(WB), Qu = lu + B'Vx (row i < m);  Qx = lx + A'Vx
+    od_row_mac<N, N>(Qxx, W, Ac);
+    od_row_mac<M, N>(QuxT, WB, Ac);
+    od_row_mac<M, N>(Quu, WB, Bc);
+    od_row_mac<1, N>(&Qx, &vx, Ac);
+    od_row_mac<1, N>(&Qu, &vx, Bc);
+    // the m x m block in every lane: Quu, Qu; Cholesky of Quu + reg I
+    double QuuR[M][M], QuR[M], L[M][M];
+    od_row_replicate<0, M>(Quu, QuuR);
+    od_row_replicate1<0, M>(Qu, QuR);
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+      double d = QuuR[c][c] + a.reg;
+#pragma unroll
+      for (int l = 0; l < c; ++l) d -= L[c][l] * L[c][l];
+      if (!(d > 0.0)) { okf = 0; d = 1e-12; }
+      const double id = od::od_rsqrt(d);      // (seed + Newton steps, < 1 ulp: od_math.h; the diagonal holds 1 / L[c][c])
+      L[c][c] = id;
+#pragma unroll
+      for (int r = c + 1; r < M; ++r) {
+        double sx = QuuR[r][c];
+#pragma unroll
+        for (int l = 0; l < c; ++l) sx -= L[r][l] * L[c][l];
+        L[r][c] = sx * id;
+      }
+    }
+    // K' row i = -(Quu + reg)^{-1} (column i of Qux);  k = -(Quu + reg)^{-1} Qu (replicated)
+    double KT[M], kR[M];
+    auto solve = [&](const double* rhs, double* y) {
+#pragma unroll
+      for (int r = 0; r < M; ++r) { double sx = rhs[r]; for (int l = 0; l < r; ++l) sx -= L[r][l] * y[l]; y[r] = sx * L[r][r]; }
+#pragma unroll
+      for (int r = M - 1; r >= 0; --r) { double sx = y[r]; for (int l = r + 1; l < M; ++l) sx -= L[l][r] * y[l]; y[r] = sx * L[r][r]; }
+#pragma unroll
+      for (int r = 0; r < M; ++r) y[r] = -y[r];
+    };
+    solve(QuxT, KT);
+    solve(QuR, kR);
+    if (live && i < N) {
+#pragma unroll
+      for (int j = 0; j < M; ++j) a.K.at(j + M * i, kk) = KT[j];
+    }
+    if (live && i < M) {
+      double kv = kR[0];
+#pragma unroll
+      for (int r = 1; r < M; ++r) kv = (i == r) ? kR[r] : kv;
+      a.k.at(i, kk) = kv;
+    }
+    // Quu k, the expected decrease, Quu K + Qux (column i)
+    double Quuk[M], G[M];
+    double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < M; ++r) { double sx = 0.0; for (int l = 0; l < M; ++l) sx += QuuR[r][l] * kR[l]; Quuk[r] = sx; }
+#pragma unroll
+    for (int r = 0; r < M; ++r) { d1 += kR[r] * QuR[r]; d2 += 0.5 * kR[r] * Quuk[r]; }
+    dV0 += d1; dV1 += d2;
+#pragma unroll
+    for (int r = 0; r < M; ++r) { double sx = 0.0; for (int l = 0; l < M; ++l) sx += QuuR[r][l] * KT[l]; G[r] = sx + QuxT[r]; }
+    // value function: Vx, Vxx (row i), symmetrised through the transpose pad
+    double vxn = Qx;
+#pragma unroll
+    for (int l = 0; l < M; ++l) vxn += KT[l] * (Quuk[l] + QuR[l]) + QuxT[l] * kR[l];
+    vx = vxn;
+    od_row_vxx_terms<0, N, M>(Qxx, G, KT, QuxT);
+    __syncthreads();                                   // (the previous knot's column reads are done)
+#pragma unroll
+    for (int c = 0; c < N; ++c) pad[rw][i * OD_IL_ROW_PAD + c] = Qxx[c];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < N; ++c) Vr[c] = (c == ir) ? Qxx[c] : 0.5 * (Qxx[c] + pad[rw][c * OD_IL_ROW_PAD + ir]);
+  }
+  if (live && i == 0) {
+    a.dV.at(0, b) = dV0;
+    a.dV.at(1, b) = dV1;
+    if (a.status.ok()) a.status.at(0, b) = okf;
+  }
+}
+
 // doubles of LDS per trajectory of a workgroup
 static inline size_t od_il_lds_per_traj(int n, int m) { return (size_t)4 * n * n + 5 * n * m + 2 * m * m + 2 * n + 3 * m + 2 + 1; }
 
@@ -1053,6 +1592,16 @@ int od_ilqr_backward(od_handle h, long B, int T, int n, int m, const void* A, co
     // ... but never fewer than 1024 workgroups while the batch allows (a workgroup of TB trajectories takes TB times as long:
     // measured on the rocket, T = 60, ms per iLQR iteration: 4096 trajectories 7.10 (one per workgroup) / 6.48 (two) / 5.67 (four) / 6.00 (eight);
     // 1024 trajectories 4.30 (one) / 4.53 (two) / 5.02 (eight))
+    if (L == OD_LAYOUT_BATCH_MINOR && h->coop != 1) {        // (od_set_cooperative(h, 1): the LDS kernels below)
+      bool done = true;
+      const dim3 g = od_grid(B, OD_IL_THREADS / 16), blk(OD_IL_THREADS);
+      if (n == 12 && m == 3) hipLaunchKernelGGL((k_ilqr_backward_row<12, 3>), g, blk, 0, h->stream, a);        // rocket
+      else if (n == 8 && m == 2) hipLaunchKernelGGL((k_ilqr_backward_row<8, 2>), g, blk, 0, h->stream, a);     // hopper
+      else if (n == 4 && m == 1) hipLaunchKernelGGL((k_ilqr_backward_row<4, 1>), g, blk, 0, h->stream, a);     // acrobot, cartpole
+      else if (n == 10 && m == 2) hipLaunchKernelGGL((k_ilqr_backward_row<10, 2>), g, blk, 0, h->stream, a);   // planar push
+      else done = false;
+      if (done) { OD_HIP(hipGetLastError()); return OD_OK; }
+    }
     int tb = (L != OD_LAYOUT_BATCH_MINOR) ? 1 : (8 * per <= 65536 ? 8 : (4 * per <= 65536 ? 4 : (2 * per <= 65536 ? 2 : 1)));
     while (tb > 1 && B / tb < 1024) tb >>= 1;
 #define OD_IL_LAUNCH(TB_, N_, M_) hipLaunchKernelGGL((k_ilqr_backward_tb<TB_, N_, M_>), od_grid(B, TB_), dim3(OD_IL_THREADS), TB_ * per, h->stream, a)

@@ -102,8 +102,17 @@ def check_backward_sizes(lib, device, sizes=((12, 3), (8, 2), (4, 1), (10, 2), (
             dV = torch.empty(2, B, dtype=torch.float64, device=device); st = torch.empty(B, dtype=torch.int32, device=device)
             args = [col(A), col(Bm), col(lxx), col(luu), col(lux), dev(lx), dev(lu), col(Vxx), dev(Vx)]
             im._use_current_stream()
+            # the workgroup kernels (matrices in LDS) first, then the default: one trajectory per 16-lane DPP row where m <= 4
+            im.set_cooperative(1)
             lib.check(lib.cdll.od_ilqr_backward(im._h, B, T, n, m, *[_ptr(a) for a in args], 1e-6, _ptr(K), _ptr(k), _ptr(dV), _ptr(st)))
             assert (st == 1).all(), (n, m, B)
+            Kl, kl, dVl = K.clone(), k.clone(), dV.clone()
+            im.set_cooperative(0)
+            K.zero_(); k.zero_(); dV.zero_(); st.zero_()
+            lib.check(lib.cdll.od_ilqr_backward(im._h, B, T, n, m, *[_ptr(a) for a in args], 1e-6, _ptr(K), _ptr(k), _ptr(dV), _ptr(st)))
+            assert (st == 1).all(), (n, m, B)
+            rel = lambda x, y: ((x - y).abs().max() / y.abs().max().clamp(min=1.0)).item()
+            assert rel(K, Kl) < 1e-10 and rel(k, kl) < 1e-10 and rel(dV, dVl) < 1e-10, (n, m, B, rel(K, Kl), rel(k, kl), rel(dV, dVl))
             Kh, kh, dVh = K.cpu().numpy(), k.cpu().numpy(), dV.cpu().numpy()
             for b in sorted({0, 1, B // 2, B - 2, B - 1}):
                 mv = lambda M: np.moveaxis(M[..., b], -1, 0)        # (r, c, T) -> (T, r, c)
