@@ -429,14 +429,13 @@ __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward_tb(IlqrArgs a) 
 // ONE TRAJECTORY PER 16-LANE DPP ROW (round 3; batch-minor data, m <= 4).  Lane i of the row keeps ROW i of every n-column
 // matrix in registers (Vxx, A, A', W = Vxx A, Qxx, the new Vxx) and row i of the m-column ones (B, W B, Qux', K'); an inner product
 // over the rows of another matrix reads them from their lanes with `v_fmac_f64_dpp row_newbcast` -- the instruction of the
-// cooperative solve kernels (od_coop.h) -- four to an asm block behind one `s_nop 1` (the DPP read-after-write hazard is not
-// interlocked on gfx950).  The m x m block (Quu, its Cholesky factor, k) is replicated in every lane.  No LDS traffic except the
-// transpose for the symmetrisation of Vxx, no workgroup barrier inside a knot but that one; 16 trajectories per workgroup, four
+// cooperative solve kernels (od_coop.h) -- up to sixteen to an asm block behind one `s_nop 1` (the DPP read-after-write hazard is not
+// interlocked on gfx950).  The m x m block (Quu, its Cholesky factor, k) is replicated in every lane.  Transposes go through a padded
+// LDS tile per row without any workgroup barrier (see the kernel); 16 trajectories per workgroup, four
 // per wavefront: 4096 trajectories are 1024 wavefronts, one per SIMD.  Sums run over the same terms as the kernels above in the
 // same order, fused (fmac) where those round the product first: results agree to rounding, not bit for bit.
 // acc[c] += sum_{l = L0 .. L0 + LW - 1} (y[c] of lane l) * x[l]  for c = 0 .. CW - 1: one asm block, the CW accumulators interleaved
-// (a chain of dependent v_fmac_f64_dpp on ONE accumulator issues at a quarter of the rate; the compiler cannot interleave
-// separate asm blocks)
+// (the compiler cannot interleave separate asm blocks; measured neutral for a lone wavefront, profiles/r3_riccati_kernels.txt)
 template <int CW, int LW, int L0> __device__ __forceinline__ void od_row_block(double* acc, const double* y, const double* x) {
   if constexpr (CW == 4 && LW == 4) {
       asm("s_nop 1\n\t"
@@ -837,7 +836,12 @@ constexpr int OD_IL_ROW_PAD = 17;     // doubles per row of the transpose pad (1
 template <int N, int M>
 __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward_row(IlqrArgs a) {
   static_assert(N <= 16 && M <= 4 && M <= N, "one matrix row per lane of a 16-lane DPP row; the m x m block is replicated");
+  // transposes go through LDS, each row of lanes in its own pad: rows of A -> columns of A, rows of B -> columns of B at the start
+  // of a knot, the new Vxx at its end.  Writer and reader lanes belong to ONE wavefront, whose LDS operations execute in order:
+  // a scheduling fence for the compiler, no workgroup barrier
   __shared__ double pad[OD_IL_THREADS / 16][16 * OD_IL_ROW_PAD];
+  __shared__ double padb[OD_IL_THREADS / 16][16 * (M + 1)];
+#define OD_IL_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
   const int tid = threadIdx.x, i = tid & 15, rw = tid >> 4;
   const long b = (long)blockIdx.x * (OD_IL_THREADS / 16) + rw;
   const bool live = b < a.B;
@@ -858,11 +862,9 @@ __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward_row(IlqrArgs a)
 #pragma unroll
     for (int j = 0; j < M; ++j) Br[j] = a.Bm.at(ir + N * j, kq);
   };
-  auto request_b = [&](long kq) {      // the transposes and the cost expansion
+  auto request_b = [&](long kq) {      // the cost expansion
 #pragma unroll
-    for (int c = 0; c < N; ++c) { Ac[c] = a.A.at(c + N * ir, kq); lxr[c] = a.lxx.at(ir + N * c, kq); }
-#pragma unroll
-    for (int c = 0; c < N; ++c) Bc[c] = a.Bm.at(c + N * im, kq);
+    for (int c = 0; c < N; ++c) lxr[c] = a.lxx.at(ir + N * c, kq);
 #pragma unroll
     for (int j = 0; j < M; ++j) { luxT[j] = a.lux.at(j + M * ir, kq); luur[j] = a.luu.at(im + M * j, kq); }
     lxv = a.lx.at(ir, kq);
@@ -873,6 +875,15 @@ __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward_row(IlqrArgs a)
     const long kk = (long)t * a.B + bb;
     double W[N], WB[M], Qxx[N], QuxT[M], Quu[M], Qx, Qu;
     request_b(kk);
+    // columns of A and B (rows of A', B') from the rows the lanes hold
+#pragma unroll
+    for (int c = 0; c < N; ++c) pad[rw][i * OD_IL_ROW_PAD + c] = Ar[c];
+#pragma unroll
+    for (int j = 0; j < M; ++j) padb[rw][i * (M + 1) + j] = Br[j];
+    OD_IL_WAVE_SYNC();
+#pragma unroll
+    for (int l = 0; l < N; ++l) { Ac[l] = pad[rw][l * OD_IL_ROW_PAD + ir]; Bc[l] = padb[rw][l * (M + 1) + im]; }
+    OD_IL_WAVE_SYNC();
     // W = Vxx A, WB = Vxx B  (row i)
 #pragma unroll
     for (int c = 0; c < N; ++c) W[c] = 0.0;
@@ -951,13 +962,14 @@ __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward_row(IlqrArgs a)
     for (int l = 0; l < M; ++l) vxn += KT[l] * (Quuk[l] + QuR[l]) + QuxT[l] * kR[l];
     vx = vxn;
     od_row_vxx_terms<0, N, M>(Qxx, G, KT, QuxT);
-    __syncthreads();                                   // (the previous knot's column reads are done)
 #pragma unroll
     for (int c = 0; c < N; ++c) pad[rw][i * OD_IL_ROW_PAD + c] = Qxx[c];
-    __syncthreads();
+    OD_IL_WAVE_SYNC();
 #pragma unroll
     for (int c = 0; c < N; ++c) Vr[c] = (c == ir) ? Qxx[c] : 0.5 * (Qxx[c] + pad[rw][c * OD_IL_ROW_PAD + ir]);
+    OD_IL_WAVE_SYNC();
   }
+#undef OD_IL_WAVE_SYNC
   if (live && i == 0) {
     a.dV.at(0, b) = dV0;
     a.dV.at(1, b) = dV1;
