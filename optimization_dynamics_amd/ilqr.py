@@ -90,6 +90,18 @@ class ILQR:
         X, A, Bm, st, it, _ = self.im.rollout(x1, U)
         return X, A, Bm, st
 
+    def linearize_at(self, X, U):
+        """fx / fu on the knots of a trajectory whose states are known already (the accepted candidates of the forward pass):
+        T*B independent knots in one launch instead of a second time recursion.  -> A (n, n, T, B), Bm (n, m, T, B)"""
+        n, m, T = self.n, self.m, self.T
+        B = U.shape[-1]
+        Xk, Uk = X[:, :-1].reshape(n, T * B), U.reshape(m, T * B)
+        if isinstance(self.im, ImplicitDynamics):
+            _, DX, DU, _, _ = self.im.step_grad(Xk, Uk)
+        else:
+            DX, DU = self.im.linearize_knots(Xk, Uk)
+        return DX.unflatten(-1, (T, B)), DU.unflatten(-1, (T, B))
+
     def backward(self, A, Bm, quad, reg):
         lxx, luu, lux, lx, lu, VxxT, VxT = quad
         n, m, T = self.n, self.m, self.T
@@ -123,7 +135,11 @@ class ILQR:
         return Xc, Uc, st
 
     # -- solver --------------------------------------------------------------------------------
-    def solve(self, x1, U0, max_iter=50, max_al_iter=1, rho_init=1.0, rho_scale=10.0, con_tol=1e-3, obj_tol=1e-6, verbose=False):
+    def solve(self, x1, U0, max_iter=50, max_al_iter=1, rho_init=1.0, rho_scale=10.0, con_tol=1e-3, obj_tol=1e-6, verbose=False,
+              reuse_forward_states=True):
+        """reuse_forward_states: the accepted candidate of the forward pass IS the new nominal trajectory (its states were
+        computed by the same time recursion), so the iteration linearises on those states knot by knot instead of rolling the
+        trajectory out a second time (False: the second rollout, as a check)"""
         im, obj = self.im, self.obj
         x1 = im._prep(x1)
         U = im._prep(U0).clone()
@@ -168,8 +184,13 @@ class ILQR:
                 Jn = torch.where(took, Jc.reshape(-1)[sel], J)
                 dJ = (J - Jn)
                 if took.any():                                   # nothing moved: the linearisation is still valid
-                    X, A, Bm, st = self.linearize(x1, U)
-                    J = obj.value(X, U, lam, rho)
+                    if reuse_forward_states:
+                        X = torch.where(took[None, None, :], Xc[:, :, sel], X)
+                        A, Bm = self.linearize_at(X, U)
+                        J = Jn
+                    else:
+                        X, A, Bm, st = self.linearize(x1, U)
+                        J = obj.value(X, U, lam, rho)
                 history.append(J.clone())
                 if verbose:
                     print("al %d it %d  J mean %.6g  accepted %d/%d  max dJ %.3g" % (al, it, J.mean().item(), int(took.sum()), B, dJ.max().item()))

@@ -134,6 +134,11 @@ class RocketDynamics:
             Bm = DU.reshape(12, 3, T, B).double()
         return X.double(), A, Bm, st, None, None
 
+    def linearize_knots(self, Xk, Uk):
+        """fx / fu (projection chain rule included) on independent knots: Xk (12, K), Uk (3, K) -> (12, 12, K), (12, 3, K)"""
+        _, DX, DU, _, _ = self.info.solve(Xk, Uk, project=self.project, grads=True)
+        return DX.double(), DU.double()
+
     def rollout_policy(self, x1, X, U, K, k, alphas):
         Xc, Uc, st = _rocket_rollout(self.info, x1, U, self.project, policy=(alphas, X, K, k))
         return Xc.double(), Uc.double(), st

@@ -144,6 +144,19 @@ def check_solver_decreases_cost(lib, device, B=8, T=25):
     return J0, Jf
 
 
+def check_reused_forward_states(lib, device, B=8, T=25):
+    """the iteration linearises on the states its forward pass computed for the accepted candidate; rolling the accepted controls
+    out a second time (reuse_forward_states=False) must give the same optimisation: costs equal to rounding, iteration by iteration"""
+    im, obj, x1, U0 = cartpole_problem(lib, device, B, T, seed=1)
+    x1t, Ut = torch.tensor(x1, device=device), torch.tensor(U0, device=device)
+    a = IL.ILQR(im, obj, T).solve(x1t, Ut, max_iter=10, max_al_iter=1)
+    b = IL.ILQR(im, obj, T).solve(x1t, Ut, max_iter=10, max_al_iter=1, reuse_forward_states=False)
+    assert len(a[3]) == len(b[3])
+    for ja, jb in zip(a[3], b[3]):
+        assert ((ja - jb).abs() <= 1e-9 * jb.abs().clamp(min=1.0)).all()
+    assert (a[0] - b[0]).abs().max().item() < 1e-8 and (a[1] - b[1]).abs().max().item() < 1e-8
+
+
 def check_one_bad_trajectory_does_not_hurt_the_batch(lib, device, B=4, T=20):
     """a trajectory whose linearisation is not finite (NaN control: a failed contact solve looks the same) keeps its backward
     pass from factorising at any regularisation; the others must converge exactly as they do without it"""

@@ -61,3 +61,12 @@ def test_rocket_projection_ilqr_gpu_f64(oracle, gpu_lib):
 def test_rocket_projection_ilqr_gpu_f32(oracle, gpu_lib):
     import torch
     C.check_rocket_ilqr(oracle, gpu_lib, "cuda:0", B=64, T=40, dtype=torch.float32)
+
+
+def test_reused_forward_states_cpu(emu_lib):
+    C.check_reused_forward_states(emu_lib, "cpu", B=4, T=15)
+
+
+@pytest.mark.gpu
+def test_reused_forward_states_gpu(gpu_lib):
+    C.check_reused_forward_states(gpu_lib, "cuda:0")
