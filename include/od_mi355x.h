@@ -158,6 +158,15 @@ int od_ilqr_backward(od_handle h, long B, int T, int n, int m, const void* A, co
                      const void* luu, const void* lux, const void* lx, const void* lu, const void* VxxT,
                      const void* VxT, double reg, void* K, void* k, void* dV, int* status);
 
+/* Cost of P trajectories under a quadratic objective (the stage / terminal costs of the reference's examples, e.g.
+ * examples/hopper.jl:207-220; the Armijo test of the forward pass evaluates it on every candidate):
+ *   J_p = sum_{t<T} 1/2 (x_t - xref)'Q(x_t - xref) + 1/2 u_t'R u_t  +  1/2 (x_T - xref)'QT(x_T - xref).
+ * X: n per slot ((T+1)*P), U: m per knot (T*P), in the handle's layout and of element type `dtype` (OD_F64 / OD_F32: the
+ * states a single-precision rocket handle rolled out are read as they are); Q, QT (n x n), R (m x m) col-major, xref (n) and J (P)
+ * are doubles on the device.  n <= 16, m <= 12.  One pass over X and U. */
+int od_quad_cost(od_handle h, long P, int T, int n, int m, int dtype, const void* X, const void* U, const double* Q,
+                 const double* R, const double* QT, const double* xref, double* J);
+
 /* gradient! (src/gradient_bundle.jl:87-104) for B knots: N+1 eval-simulator steps per knot with the
  * caller's perturbations eta ((2nq+nu) x N col-major, shared by all knots; the reference draws them
  * in the GradientBundle constructor :49-54) followed by the least-squares fit of src/ls.jl:44-60.

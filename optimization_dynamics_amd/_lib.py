@@ -64,6 +64,7 @@ SIGNATURES = {
     "od_rollout": (C.c_int, [_VP, C.c_long, C.c_int, _VP, _VP, _VP, _VP, _VP, _IP, _IP]),
     "od_rollout_compact": (C.c_int, [_VP, C.c_long, C.c_int, _VP, _VP, _VP, _VP, _IP, _IP]),
     "od_rollout_policy": (C.c_int, [_VP, C.c_long, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _IP, _IP]),
+    "od_quad_cost": (C.c_int, [_VP, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "od_ilqr_backward": (C.c_int, [_VP, C.c_long, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_double, _VP, _VP, _VP, _IP]),
     "od_bundle_workspace_bytes": (C.c_size_t, [_VP, C.c_long, C.c_int]),
     "od_bundle_grad": (C.c_int, [_VP, C.c_long, C.c_int, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _IP]),

@@ -1639,6 +1639,103 @@ int od_ilqr_backward(od_handle h, long B, int T, int n, int m, const void* A, co
   return OD_OK;
 }
 
+// ---- quadratic trajectory cost (od_quad_cost): one lane per trajectory, one pass over X and U -------------------------------
+extern "C++" {
+namespace {
+template <class T> struct QuadCostArgs {
+  long P; int Tn, n, m;
+  View<const T> X, U;
+  const double *Q, *R, *QT, *xref;
+  double* J;
+};
+// 64 consecutive trajectories per workgroup; its four wavefronts take the knots t = w, w + 4, ... and their partial sums are added
+// in a fixed order (the cost decides the Armijo test: it must not depend on scheduling).  N, M: compile-time sizes (0: any)
+template <class T, int N, int M> __global__ __launch_bounds__(256) void k_quad_cost(QuadCostArgs<T> a) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long p = (long)blockIdx.x * 64 + l;
+  const long pp = p < a.P ? p : a.P - 1;
+  const int n = N ? N : a.n, m = N ? M : a.m;
+  constexpr int NV = N ? N : OD_IL_N, MV = N ? (M ? M : 1) : OD_IL_M;
+#if defined(__HIPCC__)
+  __shared__ double part[4][64];
+  const int w0 = w, w1 = w + 1;
+#else                                      // host test build (threads run one after the other): the first wavefront's lane does all four
+  double part[4][64];
+  if (w != 0) return;
+  const int w0 = 0, w1 = 4;
+#endif
+  for (int wq = w0; wq < w1; ++wq) {
+  double J = 0.0;
+  for (int t = wq; t <= a.Tn; t += 4) {
+    const long ks = (long)t * a.P + pp;
+    double v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = i < n ? (double)a.X.at(i, ks) - a.xref[i] : 0.0;
+    const double* Mx = (t < a.Tn) ? a.Q : a.QT;
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      double r = 0.0;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) r += (i < n && j < n) ? Mx[i + n * j] * v[j] : 0.0;
+      s += v[i] * r;
+    }
+    J += 0.5 * s;
+    if (t < a.Tn) {
+      double u[MV];
+#pragma unroll
+      for (int i = 0; i < MV; ++i) u[i] = i < m ? (double)a.U.at(i, ks) : 0.0;
+      double su = 0.0;
+#pragma unroll
+      for (int i = 0; i < MV; ++i) {
+        double r = 0.0;
+#pragma unroll
+        for (int j = 0; j < MV; ++j) r += (i < m && j < m) ? a.R[i + m * j] * u[j] : 0.0;
+        su += u[i] * r;
+      }
+      J += 0.5 * su;
+    }
+  }
+  part[wq][l] = J;
+  }
+#if defined(__HIPCC__)
+  __syncthreads();
+#endif
+  if (w == 0 && p < a.P) a.J[p] = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
+}
+}  // namespace
+}  // extern "C++"
+
+int od_quad_cost(od_handle h, long P, int T, int n, int m, int dtype, const void* X, const void* U, const double* Q,
+                 const double* R, const double* QT, const double* xref, double* J) {
+  if (!h) return fail(OD_ERR_INVALID, "od_quad_cost: null handle");
+  if (P <= 0) return OD_OK;
+  if (T <= 0 || n <= 0 || m <= 0 || n > OD_IL_N || m > OD_IL_M) return fail(OD_ERR_INVALID, "od_quad_cost: T >= 1, n <= 16, m <= 12");
+  if (dtype != OD_F64 && dtype != OD_F32) return fail(OD_ERR_INVALID, "od_quad_cost: dtype OD_F64 or OD_F32");
+  if (!X || !U || !Q || !R || !QT || !xref || !J) return fail(OD_ERR_INVALID, "od_quad_cost: null argument");
+  const int L = h->layout;
+#define OD_QC_LAUNCH(T_, N_, M_) hipLaunchKernelGGL((k_quad_cost<T_, N_, M_>), od_grid(P, 64), dim3(256), 0, h->stream, a)
+#define OD_QC_SIZES(T_)                                                                                   \
+  do {                                                                                                    \
+    if (n == 12 && m == 3) OD_QC_LAUNCH(T_, 12, 3);                                                       \
+    else if (n == 8 && m == 2) OD_QC_LAUNCH(T_, 8, 2);                                                    \
+    else if (n == 4 && m == 1) OD_QC_LAUNCH(T_, 4, 1);                                                    \
+    else if (n == 10 && m == 2) OD_QC_LAUNCH(T_, 10, 2);                                                  \
+    else OD_QC_LAUNCH(T_, 0, 0);                                                                          \
+  } while (0)
+  if (dtype == OD_F64) {
+    QuadCostArgs<double> a{P, T, n, m, mkcview<double>(X, n, (long)(T + 1) * P, L), mkcview<double>(U, m, (long)T * P, L), Q, R, QT, xref, J};
+    OD_QC_SIZES(double);
+  } else {
+    QuadCostArgs<float> a{P, T, n, m, mkcview<float>(X, n, (long)(T + 1) * P, L), mkcview<float>(U, m, (long)T * P, L), Q, R, QT, xref, J};
+    OD_QC_SIZES(float);
+  }
+#undef OD_QC_SIZES
+#undef OD_QC_LAUNCH
+  OD_HIP(hipGetLastError());
+  return OD_OK;
+}
+
 size_t od_bundle_workspace_bytes(od_handle h, long B, int N) {
   if (!h || B <= 0 || N <= 0) return 0;
   const size_t nq = h->vt->nq, nzb = 2 * nq + h->vt->nu;

@@ -36,16 +36,36 @@ class QuadraticObjective:
         """c = x_T[idx] - goal, shape (nc, P)"""
         return X[self.goal_idx, -1, :] - self.goal[:, None]
 
+    def bind(self, im):
+        """use the library's one-pass cost kernel (od_quad_cost) through this dynamics object's handle"""
+        self._im = im
+        self._cm = tuple(M.T.contiguous() for M in (self.Q, self.R, self.QT))       # column-major flattenings
+
+    def _value_kernel(self, X, U):
+        from ._lib import OD_F32, OD_F64
+        im = self._im
+        X, U = X.contiguous(), U.contiguous()
+        T, P = U.shape[1], U.shape[2]
+        J = torch.empty(P, dtype=torch.float64, device=X.device)
+        im._use_current_stream()
+        im.lib.check(im.lib.cdll.od_quad_cost(im._h, P, T, self.n, self.m, OD_F32 if X.dtype == torch.float32 else OD_F64, _ptr(X), _ptr(U),
+                                              _ptr(self._cm[0]), _ptr(self._cm[1]), _ptr(self._cm[2]), _ptr(self.x_ref), _ptr(J)))
+        return J
+
     def value(self, X, U, lam=None, rho=0.0):
         """X: (n, T+1, P), U: (m, T, P) -> cost per trajectory (P,)"""
-        dx = X - self.x_ref[:, None, None]
         T, P = U.shape[1], U.shape[2]
+        if getattr(self, "_im", None) is not None and X.dtype == U.dtype and X.dtype in (torch.float32, torch.float64) \
+                and X.device == self.x_ref.device and self.n <= 16 and self.m <= 12:
+            J = self._value_kernel(X, U)
+        else:
+            dx = X.double() - self.x_ref[:, None, None]
 
-        def quad(M, v):                     # sum over knots of 1/2 v'Mv per trajectory: one skinny GEMM, not an einsum
-            vf = v.reshape(v.shape[0], -1)
-            return 0.5 * (vf * (M @ vf)).sum(0).view(-1, P).sum(0)
+            def quad(M, v):                     # sum over knots of 1/2 v'Mv per trajectory: one skinny GEMM, not an einsum
+                vf = v.reshape(v.shape[0], -1)
+                return 0.5 * (vf * (M @ vf)).sum(0).view(-1, P).sum(0)
 
-        J = quad(self.Q, dx[:, :-1]) + quad(self.R, U) + quad(self.QT, dx[:, -1])
+            J = quad(self.Q, dx[:, :-1]) + quad(self.R, U.double()) + quad(self.QT, dx[:, -1])
         if self.goal_idx is not None and lam is not None:
             c = self.constraint(X)
             J = J + (lam * c).sum(0) + 0.5 * rho * (c * c).sum(0)
@@ -84,6 +104,8 @@ class ILQR:
             self.n, self.m = im.n, im.m
         self.alphas = torch.tensor(alphas, dtype=torch.float64, device=im.device)
         self.reg, self.c1 = reg, c1
+        if hasattr(objective, "bind"):
+            objective.bind(im)
 
     # -- the three device steps ----------------------------------------------------------------
     def linearize(self, x1, U):
@@ -180,12 +202,12 @@ class ILQR:
                 first = torch.where(accept.any(0), accept.float().argmax(0), torch.full((B,), -1, device=im.device, dtype=torch.long))
                 took = first >= 0
                 sel = torch.clamp(first, min=0) * B + torch.arange(B, device=im.device)
-                U = torch.where(took[None, None, :], Uc[:, :, sel], U)
+                U = torch.where(took[None, None, :], Uc[:, :, sel].double(), U)
                 Jn = torch.where(took, Jc.reshape(-1)[sel], J)
                 dJ = (J - Jn)
                 if took.any():                                   # nothing moved: the linearisation is still valid
                     if reuse_forward_states:
-                        X = torch.where(took[None, None, :], Xc[:, :, sel], X)
+                        X = torch.where(took[None, None, :], Xc[:, :, sel].double(), X)
                         A, Bm = self.linearize_at(X, U)
                         J = Jn
                     else:

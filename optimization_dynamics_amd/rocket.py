@@ -141,7 +141,7 @@ class RocketDynamics:
 
     def rollout_policy(self, x1, X, U, K, k, alphas):
         Xc, Uc, st = _rocket_rollout(self.info, x1, U, self.project, policy=(alphas, X, K, k))
-        return Xc.double(), Uc.double(), st
+        return Xc, Uc, st            # (the handle's element type: od_quad_cost reads it as it is, ILQR converts what it keeps)
 
 
 def _scalar(info, x, u, project, grads):

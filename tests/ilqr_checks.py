@@ -144,6 +144,24 @@ def check_solver_decreases_cost(lib, device, B=8, T=25):
     return J0, Jf
 
 
+def check_quad_cost(lib, device):
+    """od_quad_cost (one pass over X and U) against the formula in torch, double and single precision inputs, dense Q / R / QT"""
+    import parity_checks as P
+    im = P.make_im("cartpole_friction", lib, device)
+    for n, m, T, Pn in ((4, 1, 7, 33), (12, 3, 5, 1000), (16, 12, 3, 65)):
+        rng = np.random.default_rng(n + m)
+        sym = lambda k: (lambda G: G @ G.T + np.eye(k))(rng.normal(size=(k, k)))
+        obj = IL.QuadraticObjective(sym(n), sym(m), sym(n), rng.normal(size=n), device=device)
+        X = torch.tensor(rng.normal(size=(n, T + 1, Pn)), device=device); U = torch.tensor(rng.normal(size=(m, T, Pn)), device=device)
+        ref = obj.value(X, U)                                   # (not bound: the torch formula)
+        obj.bind(im)
+        got = obj.value(X, U)
+        assert ((got - ref).abs() <= 1e-12 * ref.abs().clamp(min=1.0)).all()
+        got32 = obj.value(X.float(), U.float())
+        ref32 = IL.QuadraticObjective(obj.Q.cpu().numpy(), obj.R.cpu().numpy(), obj.QT.cpu().numpy(), obj.x_ref.cpu().numpy(), device=device).value(X.float().double(), U.float().double())
+        assert ((got32 - ref32).abs() <= 1e-12 * ref32.abs().clamp(min=1.0)).all()
+
+
 def check_reused_forward_states(lib, device, B=8, T=25):
     """the iteration linearises on the states its forward pass computed for the accepted candidate; rolling the accepted controls
     out a second time (reuse_forward_states=False) must give the same optimisation: costs equal to rounding, iteration by iteration"""

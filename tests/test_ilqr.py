@@ -70,3 +70,12 @@ def test_reused_forward_states_cpu(emu_lib):
 @pytest.mark.gpu
 def test_reused_forward_states_gpu(gpu_lib):
     C.check_reused_forward_states(gpu_lib, "cuda:0")
+
+
+def test_quad_cost_cpu(emu_lib):
+    C.check_quad_cost(emu_lib, "cpu")
+
+
+@pytest.mark.gpu
+def test_quad_cost_gpu(gpu_lib):
+    C.check_quad_cost(gpu_lib, "cuda:0")
