@@ -70,5 +70,6 @@ def test_rocket_and_riccati_in_a_graph(gpu_lib):
     def run():
         X, A, Bm, st, _, _ = dyn.rollout(x1t, Ut)                       # od_rocket_rollout + od_rocket on every knot
         K, k, dV, bst = solver.backward(A, Bm, obj.expansion(X, Ut.double(), lam, 1.0), 1e-6)      # od_ilqr_backward
-        return X, A, Bm, K, k, dV
+        J = obj.value(X, Ut.double())                                                               # od_quad_cost
+        return X, A, Bm, K, k, dV, J
     _capture_replay(run, lambda: Ut.add_(0.02), lambda o: o)
