@@ -167,6 +167,66 @@ int od_ilqr_backward(od_handle h, long B, int T, int n, int m, const void* A, co
 int od_quad_cost(od_handle h, long P, int T, int n, int m, int dtype, const void* X, const void* U, const double* Q,
                  const double* R, const double* QT, const double* xref, double* J);
 
+/* ---- the whole iLQR iteration on the device -----------------------------------------------------------
+ * iLQR.solver / iLQR.solve! of IterativeLQR.jl as the reference drives it (examples/acrobot.jl:97-113, examples/rocket.jl:118-139)
+ * for B independent problems in lockstep: quadratic stage / terminal objective (od_quad_cost) and terminal equality
+ * constraints x_T[idx] = goal by augmented Lagrangian (the examples' terminal_con).  One iteration =
+ *   expansion of the cost | Riccati backward pass (a trajectory whose Quu + reg I is not positive definite repeats its own
+ *   recursion at 10x the regularisation, up to 1e6) | closed-loop rollouts of ALL step sizes of all trajectories | their cost |
+ *   Armijo selection per trajectory | copy of the accepted candidate | linearisation (fx, fu) on its states | scalar
+ *   bookkeeping (shared regularisation schedule, convergence flag, cost history)
+ * -- nine launches on the handle's stream, NO host synchronisation, no allocation: od_ilqr_iterate can be recorded in a HIP
+ * graph.  Convergence (max dJ < obj_tol, or reg >= 1e6) sets a flag on the device that turns later iterations into empty
+ * launches, so a caller may enqueue max_iter iterations blindly.  The handle may be a mechanical model (n = 2nq, m = nu:
+ * od_rollout_policy / od_step_grad underneath) or OD_ROCKET_DYNAMICS in OD_F64 / OD_F32 (n = 12, m = 3: od_rocket_rollout /
+ * od_rocket with or without the thrust-cone projection).  Batch-minor layout only.  The solver borrows the handle: no other
+ * call on the handle while solver work is in flight, and the handle must outlive the solver. */
+typedef struct od_ilqr_s* od_ilqr;
+typedef struct {
+  double reg;          /* initial / minimal regularisation of Quu (1e-6)                                   */
+  double c1;           /* Armijo constant (1e-4)                                                           */
+  double obj_tol;      /* inner loop ends when an iteration improved no cost by more than this (1e-6)      */
+  double con_tol;      /* outer loop ends when max |x_T[idx] - goal| over the batch is below this (1e-3)   */
+  double rho_init, rho_scale;   /* penalty schedule (1, 10); cf. iLQR.Options, examples/acrobot.jl:98-107  */
+  int max_iter, max_al_iter;    /* (50, 1)                                                                 */
+  int project;         /* rocket handles: 1 = f_rocket_proj (thrust-cone projection on the path), 0 = f_rocket */
+  int history;         /* cost histories kept on the device: iterations (0 = max_iter * max_al_iter)      */
+} od_ilqr_options;
+typedef struct {
+  int iterations;      /* iLQR iterations run since od_ilqr_init (all augmented-Lagrangian rounds)         */
+  int al_iterations;   /* multiplier updates done                                                          */
+  int done;            /* inner loop converged (or regularisation exhausted)                               */
+  int al_done;         /* terminal constraints met to con_tol                                              */
+  int bad_linearisations;  /* knots of the current linearisation whose dynamics solve did not converge    */
+  double reg, rho, max_dJ, max_violation;
+} od_ilqr_info;
+int od_ilqr_default_options(od_ilqr_options* out);
+/* alphas: nalpha step sizes tried in this order (host pointer; e.g. 1, 1/2, ..., 2^-10).  Allocates every buffer. */
+int od_ilqr_create(od_handle h, long B, int T, int nalpha, const double* alphas, const od_ilqr_options* opts, od_ilqr* out);
+int od_ilqr_destroy(od_ilqr s);
+/* J = sum_t 1/2 (x_t - xref)'Q(x_t - xref) + 1/2 u_t'R u_t + 1/2 (x_T - xref)'QT(x_T - xref); Q, QT n x n and R m x m
+ * column-major, symmetric; ngoal terminal equality constraints x_T[goal_idx[i]] = goal[i] (ngoal = 0: none).  Host pointers. */
+int od_ilqr_set_objective(od_ilqr s, const double* Q, const double* R, const double* QT, const double* xref, int ngoal,
+                          const int* goal_idx, const double* goal);
+/* initialize_controls! + rollout + first linearisation and cost (examples/acrobot.jl:108-113): x1 n per trajectory, U0 m per knot
+ * (T*B knots), doubles on the device.  Resets multipliers, penalty, regularisation and counters.  Asynchronous. */
+int od_ilqr_init(od_ilqr s, const double* x1, const double* U0);
+/* niter iterations, asynchronous, capturable */
+int od_ilqr_iterate(od_ilqr s, int niter);
+/* augmented-Lagrangian round: violation check, lam += rho c, rho *= rho_scale, cost of the nominal trajectory under the new
+ * multipliers, regularisation reset, convergence flag cleared.  Asynchronous, capturable. */
+int od_ilqr_al_update(od_ilqr s);
+/* solve!(solver): init, then max_al_iter rounds of max_iter iterations with the multiplier update between them.  Iterations are
+ * enqueued in chunks; the host waits only for the chunk before the previous one (the queue never drains) to stop early. */
+int od_ilqr_solve(od_ilqr s, const double* x1, const double* U0);
+/* results (device pointers, doubles, any may be NULL): X n per slot ((T+1)*B), U m per knot, J per trajectory (with the
+ * multiplier terms), K (m x n col-major per knot) and k of the last backward pass.  Asynchronous. */
+int od_ilqr_get(od_ilqr s, double* X, double* U, double* J, double* K, double* k);
+/* hist: up to `cap` rows of B costs (row i = costs after iteration i), device pointer; returns the number of rows kept so far
+ * (synchronises) or a negative error */
+int od_ilqr_get_history(od_ilqr s, double* hist, int cap);
+int od_ilqr_get_info(od_ilqr s, od_ilqr_info* out);   /* synchronises the handle's stream */
+
 /* gradient! (src/gradient_bundle.jl:87-104) for B knots: N+1 eval-simulator steps per knot with the
  * caller's perturbations eta ((2nq+nu) x N col-major, shared by all knots; the reference draws them
  * in the GradientBundle constructor :49-54) followed by the least-squares fit of src/ls.jl:44-60.

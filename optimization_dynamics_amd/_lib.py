@@ -27,6 +27,20 @@ class Options(C.Structure):
                 ("undercut", C.c_double)]
 
 
+class IlqrOptions(C.Structure):
+    """od_ilqr_options (cf. iLQR.Options, examples/acrobot.jl:98-107)"""
+    _fields_ = [("reg", C.c_double), ("c1", C.c_double), ("obj_tol", C.c_double), ("con_tol", C.c_double),
+                ("rho_init", C.c_double), ("rho_scale", C.c_double), ("max_iter", C.c_int), ("max_al_iter", C.c_int),
+                ("project", C.c_int), ("history", C.c_int)]
+
+
+class IlqrInfo(C.Structure):
+    """od_ilqr_info"""
+    _fields_ = [("iterations", C.c_int), ("al_iterations", C.c_int), ("done", C.c_int), ("al_done", C.c_int),
+                ("bad_linearisations", C.c_int), ("reg", C.c_double), ("rho", C.c_double), ("max_dJ", C.c_double),
+                ("max_violation", C.c_double)]
+
+
 class ODError(RuntimeError):
     pass
 
@@ -66,6 +80,17 @@ SIGNATURES = {
     "od_rollout_policy": (C.c_int, [_VP, C.c_long, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _IP, _IP]),
     "od_quad_cost": (C.c_int, [_VP, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "od_ilqr_backward": (C.c_int, [_VP, C.c_long, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_double, _VP, _VP, _VP, _IP]),
+    "od_ilqr_default_options": (C.c_int, [C.POINTER(IlqrOptions)]),
+    "od_ilqr_create": (C.c_int, [_VP, C.c_long, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(IlqrOptions), C.POINTER(_VP)]),
+    "od_ilqr_destroy": (C.c_int, [_VP]),
+    "od_ilqr_set_objective": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "od_ilqr_init": (C.c_int, [_VP, _VP, _VP]),
+    "od_ilqr_iterate": (C.c_int, [_VP, C.c_int]),
+    "od_ilqr_al_update": (C.c_int, [_VP]),
+    "od_ilqr_solve": (C.c_int, [_VP, _VP, _VP]),
+    "od_ilqr_get": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
+    "od_ilqr_get_history": (C.c_int, [_VP, _VP, C.c_int]),
+    "od_ilqr_get_info": (C.c_int, [_VP, C.POINTER(IlqrInfo)]),
     "od_bundle_workspace_bytes": (C.c_size_t, [_VP, C.c_long, C.c_int]),
     "od_bundle_grad": (C.c_int, [_VP, C.c_long, C.c_int, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _IP]),
     "od_ls_fit": (C.c_int, [_VP, C.c_long, C.c_int, C.c_int, C.c_int, _VP, _VP, _VP, _IP]),

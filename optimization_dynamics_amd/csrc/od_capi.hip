@@ -209,21 +209,32 @@ __global__ __launch_bounds__(256) void k_ls_fit_fused(long B, int N, const doubl
 //   Qx = lx + A'Vx, Qu = lu + B'Vx, Qxx = lxx + A'Vxx A, Quu = luu + B'Vxx B + reg I, Qux = lux + B'Vxx A
 //   K = -Quu^{-1} Qux, k = -Quu^{-1} Qu, Vx = Qx + K'Quu k + K'Qu + Qux'k, Vxx = Qxx + K'Quu K + K'Qux + Qux'K
 constexpr int OD_IL_N = 16, OD_IL_M = 12;
-struct IlqrArgs {
+// TA: element type of the linearisation (A, Bm) and of the gains (K, k) -- double, or float when they come from / go to the
+// single-precision rocket kernels (the device-resident iteration, od_ilqr_solver.inc); the recursion itself runs in double.
+template <class TA> struct IlqrArgsT {
   long B; int T, n, m; double reg;
-  View<const double> A, Bm, lxx, luu, lux, lx, lu;   // per knot (T*B)
+  View<const TA> A, Bm;                              // per knot (T*B)
+  View<const double> lxx, luu, lux, lx, lu;          // per knot (a view with sb = 0 shares one matrix between all knots)
   View<const double> VxxT, VxT;                      // per trajectory
-  View<double> K, k;                                 // per knot: m x n col-major, m
+  View<TA> K, k;                                     // per knot: m x n col-major, m
   View<double> dV;                                   // per trajectory: [sum k'Qu, sum 0.5 k'Quu k]
   View<int> status;                                  // per trajectory: 1 = every Quu factorised (positive pivots)
+  // device-resident iteration (all null / 0 for od_ilqr_backward):
+  const double* reg_dev;                             // regularisation read from device memory instead of `reg`
+  int retry;                                         // 1: a trajectory whose Quu + reg I is not positive definite repeats ITS recursion with
+                                                     // reg <- min(max(reg, 1e-8) * 10, 1e6) until it factorises; still failing at 1e6: K = k = dV = 0, status 0
+  const int* skip;                                   // *skip != 0: the launch does nothing
 };
+using IlqrArgs = IlqrArgsT<double>;
+OD_HD double od_il_next_reg(double r) { return fmin(fmax(r, 1e-8) * 10.0, 1e6); }
 #if defined(__HIPCC__)
 // One 256-thread workgroup per trajectory, matrices in LDS, thread (i, j) = tid % rows, tid / rows owns one entry of
 // each small product (n <= 16: n*n <= 256 entries).  The first version ran one LANE per trajectory with dynamically
 // indexed private arrays (scratch): 53 ms per call for the rocket (n = 12, m = 3, T = 60, 4096 trajectories) -- 77 % of an
 // iLQR iteration; this one: see profiles/r1_ilqr.json.
 constexpr int OD_IL_THREADS = 256;
-__global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward(IlqrArgs a) {
+template <class TA> __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward(IlqrArgsT<TA> a) {
+  if (a.skip && *a.skip) return;
   const long b = blockIdx.x;
   const int n = a.n, m = a.m, tid = threadIdx.x;
   __shared__ double Vxx[OD_IL_N * OD_IL_N], At[OD_IL_N * OD_IL_N], W[OD_IL_N * OD_IL_N], Qxx[OD_IL_N * OD_IL_N];
@@ -236,14 +247,16 @@ __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward(IlqrArgs a) {
   // entry owned by this thread in n x n, n x m (rows n) and m x n (rows m) matrices
   const int in_ = tid % n, jn_ = tid / n;         // valid if tid < nn (n x n) or tid < nm (n x m: column jn_ < m)
   const int im_ = tid % m, jm_ = tid / m;         // valid if tid < nm (m x n: column jm_ < n) or tid < mm (m x m)
+  double reg = a.reg_dev ? *a.reg_dev : a.reg;
+  for (;;) {                                  // (one pass unless a.retry)
   if (tid < nn) Vxx[tid] = a.VxxT.at(tid, b);
   if (tid < n) Vx[tid] = a.VxT.at(tid, b);
   if (tid == 0) { dV[0] = 0.0; dV[1] = 0.0; okflag = 1; }
   __syncthreads();
   for (int t = a.T - 1; t >= 0; --t) {
     const long kk = (long)t * a.B + b;
-    if (tid < nn) At[tid] = a.A.at(tid, kk);
-    if (tid < nm) Bt[tid] = a.Bm.at(tid, kk);
+    if (tid < nn) At[tid] = (double)a.A.at(tid, kk);
+    if (tid < nm) Bt[tid] = (double)a.Bm.at(tid, kk);
     __syncthreads();
     // W = Vxx A (n x n), WB = Vxx B (n x m)
     if (tid < nn) { double s = 0; for (int l = 0; l < n; ++l) s += Vxx[in_ + n * l] * At[l + n * jn_]; W[tid] = s; }
@@ -259,7 +272,7 @@ __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward(IlqrArgs a) {
     // Cholesky of Quu + reg I (m <= 12: one thread)
     if (tid == 0) {
       for (int i = 0; i < mm; ++i) L[i] = Quu[i];
-      for (int i = 0; i < m; ++i) L[i + m * i] += a.reg;
+      for (int i = 0; i < m; ++i) L[i + m * i] += reg;
       for (int j = 0; j < m; ++j) {
         double d = L[j + m * j];
         for (int l = 0; l < j; ++l) d -= L[j + m * l] * L[j + m * l];
@@ -270,6 +283,7 @@ __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward(IlqrArgs a) {
       }
     }
     __syncthreads();
+    if (a.retry && !okflag) break;            // (uniform: okflag is shared) this pass is thrown away
     // K = -(Quu+reg)^{-1} Qux (one thread per column), k = -(Quu+reg)^{-1} Qu (thread n)
     if (tid <= n) {
       const int c = tid;
@@ -280,9 +294,9 @@ __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward(IlqrArgs a) {
       for (int i = 0; i < m; ++i) { if (c < n) Kt[i + m * c] = -y[i]; else kt[i] = -y[i]; }
     }
     __syncthreads();
-    if (tid < nm) a.K.at(tid, kk) = Kt[tid];
+    if (tid < nm) a.K.at(tid, kk) = (TA)Kt[tid];
     if (tid < m) {
-      a.k.at(tid, kk) = kt[tid];
+      a.k.at(tid, kk) = (TA)kt[tid];
       double sx = 0; for (int l = 0; l < m; ++l) sx += Quu[tid + m * l] * kt[l];
       Quuk[tid] = sx;                                             // Quu k (Quu without reg, as in the cost-to-go expansion)
     }
@@ -312,6 +326,18 @@ __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward(IlqrArgs a) {
     __syncthreads();
     if (tid < nn && in_ < jn_) { const double sx = 0.5 * (Vxx[in_ + n * jn_] + Vxx[jn_ + n * in_]); Vxx[in_ + n * jn_] = sx; Vxx[jn_ + n * in_] = sx; }
     __syncthreads();
+  }
+  if (!a.retry || okflag || !(reg < 1e6)) break;
+  reg = od_il_next_reg(reg);
+  __syncthreads();                            // (everybody has read okflag before thread 0 resets it)
+  }
+  if (a.retry && !okflag) {                   // not factorisable at any regularisation (non-finite data): no step for this trajectory
+    for (int t = 0; t < a.T; ++t) {
+      const long kk = (long)t * a.B + b;
+      if (tid < nm) a.K.at(tid, kk) = TA(0);
+      if (tid < m) a.k.at(tid, kk) = TA(0);
+    }
+    if (tid == 0) { dV[0] = 0.0; dV[1] = 0.0; }
   }
   if (tid == 0) {
     a.dV.at(0, b) = dV[0];
@@ -833,8 +859,9 @@ template <int A_, int M> __device__ __forceinline__ void od_row_replicate1(doubl
 }
 
 constexpr int OD_IL_ROW_PAD = 17;     // doubles per row of the transpose pad (16 + 1: the column reads hit 16 banks)
-template <int N, int M>
-__global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward_row(IlqrArgs a) {
+template <int N, int M, class TA = double>
+__global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward_row(IlqrArgsT<TA> a) {
+  if (a.skip && *a.skip) return;
   static_assert(N <= 16 && M <= 4 && M <= N, "one matrix row per lane of a 16-lane DPP row; the m x m block is replicated");
   // transposes go through LDS, each row of lanes in its own pad: rows of A -> columns of A, rows of B -> columns of B at the start
   // of a knot, the new Vxx at its end.  Writer and reader lanes belong to ONE wavefront, whose LDS operations execute in order:
@@ -847,8 +874,13 @@ __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward_row(IlqrArgs a)
   const bool live = b < a.B;
   const long bb = live ? b : a.B - 1;                 // (rows past the batch repeat its last trajectory, store nothing)
   const int ir = i < N ? i : N - 1, im = i < M ? i : M - 1;       // (lanes without a row repeat the last one)
-  double Vr[N], vx, dV0 = 0.0, dV1 = 0.0;
-  int okf = 1;
+  double Vr[N], vx, dV0, dV1;
+  int okf;
+  double reg = a.reg_dev ? *a.reg_dev : a.reg;
+  // (one pass unless a.retry: a row whose Quu + reg I fails to factorise repeats its own recursion at a larger reg while the
+  // other rows of the wavefront wait -- the rows share nothing but the instruction stream)
+  for (;;) {
+  dV0 = 0.0; dV1 = 0.0; okf = 1;
 #pragma unroll
   for (int c = 0; c < N; ++c) Vr[c] = a.VxxT.at(ir + N * c, bb);
   vx = a.VxT.at(ir, bb);
@@ -858,9 +890,9 @@ __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward_row(IlqrArgs a)
   double Ar[N], Br[M], Ac[N], Bc[N], lxr[N], luxT[M], luur[M], lxv, luv;
   auto request_a = [&](long kq) {      // what the first products need
 #pragma unroll
-    for (int c = 0; c < N; ++c) Ar[c] = a.A.at(ir + N * c, kq);
+    for (int c = 0; c < N; ++c) Ar[c] = (double)a.A.at(ir + N * c, kq);
 #pragma unroll
-    for (int j = 0; j < M; ++j) Br[j] = a.Bm.at(ir + N * j, kq);
+    for (int j = 0; j < M; ++j) Br[j] = (double)a.Bm.at(ir + N * j, kq);
   };
   auto request_b = [&](long kq) {      // the cost expansion
 #pragma unroll
@@ -910,7 +942,7 @@ __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward_row(IlqrArgs a)
     od_row_replicate1<0, M>(Qu, QuR);
 #pragma unroll
     for (int c = 0; c < M; ++c) {
-      double d = QuuR[c][c] + a.reg;
+      double d = QuuR[c][c] + reg;
 #pragma unroll
       for (int l = 0; l < c; ++l) d -= L[c][l] * L[c][l];
       if (!(d > 0.0)) { okf = 0; d = 1e-12; }
@@ -936,15 +968,16 @@ __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward_row(IlqrArgs a)
     };
     solve(QuxT, KT);
     solve(QuR, kR);
+    if (a.retry && !okf) break;               // (the whole row agrees: the m x m block is replicated) this pass is thrown away
     if (live && i < N) {
 #pragma unroll
-      for (int j = 0; j < M; ++j) a.K.at(j + M * i, kk) = KT[j];
+      for (int j = 0; j < M; ++j) a.K.at(j + M * i, kk) = (TA)KT[j];
     }
     if (live && i < M) {
       double kv = kR[0];
 #pragma unroll
       for (int r = 1; r < M; ++r) kv = (i == r) ? kR[r] : kv;
-      a.k.at(i, kk) = kv;
+      a.k.at(i, kk) = (TA)kv;
     }
     // Quu k, the expected decrease, Quu K + Qux (column i)
     double Quuk[M], G[M];
@@ -969,7 +1002,21 @@ __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward_row(IlqrArgs a)
     for (int c = 0; c < N; ++c) Vr[c] = (c == ir) ? Qxx[c] : 0.5 * (Qxx[c] + pad[rw][c * OD_IL_ROW_PAD + ir]);
     OD_IL_WAVE_SYNC();
   }
+  if (!a.retry || okf || !(reg < 1e6)) break;
+  reg = od_il_next_reg(reg);
+  }
 #undef OD_IL_WAVE_SYNC
+  if (a.retry && !okf) {                      // not factorisable at any regularisation (non-finite data): no step for this trajectory
+    dV0 = 0.0; dV1 = 0.0;
+    for (int t = 0; t < a.T; ++t) {
+      const long kk = (long)t * a.B + bb;
+      if (live && i < N) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) a.K.at(j + M * i, kk) = TA(0);
+      }
+      if (live && i < M) a.k.at(i, kk) = TA(0);
+    }
+  }
   if (live && i == 0) {
     a.dV.at(0, b) = dV0;
     a.dV.at(1, b) = dV1;
@@ -982,21 +1029,25 @@ static inline size_t od_il_lds_per_traj(int n, int m) { return (size_t)4 * n * n
 
 #else
 // host test build (threads run one after the other, no workgroup cooperation): one lane per trajectory
-__global__ __launch_bounds__(OD_BLOCK) void k_ilqr_backward_serial(IlqrArgs a) {
+template <class TA> __global__ __launch_bounds__(OD_BLOCK) void k_ilqr_backward_serial(IlqrArgsT<TA> a) {
+  if (a.skip && *a.skip) return;
   const long b = (long)blockIdx.x * OD_BLOCK + threadIdx.x;
   if (b >= a.B) return;
   const int n = a.n, m = a.m;
   double Vxx[OD_IL_N * OD_IL_N], Vx[OD_IL_N], At[OD_IL_N * OD_IL_N], Bt[OD_IL_N * OD_IL_M], W[OD_IL_N * OD_IL_N];
   double Qxx[OD_IL_N * OD_IL_N], Quu[OD_IL_M * OD_IL_M], Qux[OD_IL_M * OD_IL_N], Qx[OD_IL_N], Qu[OD_IL_M];
   double L[OD_IL_M * OD_IL_M], Kt[OD_IL_M * OD_IL_N], kt[OD_IL_M];
+  double dV1, dV2, reg = a.reg_dev ? *a.reg_dev : a.reg;
+  bool ok;
+  for (;;) {
   for (int i = 0; i < n * n; ++i) Vxx[i] = a.VxxT.at(i, b);
   for (int i = 0; i < n; ++i) Vx[i] = a.VxT.at(i, b);
-  double dV1 = 0.0, dV2 = 0.0;
-  bool ok = true;
+  dV1 = 0.0; dV2 = 0.0;
+  ok = true;
   for (int t = a.T - 1; t >= 0; --t) {
     const long kk = (long)t * a.B + b;
-    for (int i = 0; i < n * n; ++i) At[i] = a.A.at(i, kk);
-    for (int i = 0; i < n * m; ++i) Bt[i] = a.Bm.at(i, kk);
+    for (int i = 0; i < n * n; ++i) At[i] = (double)a.A.at(i, kk);
+    for (int i = 0; i < n * m; ++i) Bt[i] = (double)a.Bm.at(i, kk);
     // W = Vxx * A  (n x n)
     for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) { double s = 0; for (int l = 0; l < n; ++l) s += Vxx[i + n * l] * At[l + n * j]; W[i + n * j] = s; }
     for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) { double s = a.lxx.at(i + n * j, kk); for (int l = 0; l < n; ++l) s += At[l + n * i] * W[l + n * j]; Qxx[i + n * j] = s; }
@@ -1008,7 +1059,7 @@ __global__ __launch_bounds__(OD_BLOCK) void k_ilqr_backward_serial(IlqrArgs a) {
     for (int i = 0; i < m; ++i) { double s = a.lu.at(i, kk); for (int l = 0; l < n; ++l) s += Bt[l + n * i] * Vx[l]; Qu[i] = s; }
     // Cholesky of Quu + reg I
     for (int i = 0; i < m * m; ++i) L[i] = Quu[i];
-    for (int i = 0; i < m; ++i) L[i + m * i] += a.reg;
+    for (int i = 0; i < m; ++i) L[i + m * i] += reg;
     for (int j = 0; j < m; ++j) {
       double d = L[j + m * j];
       for (int l = 0; l < j; ++l) d -= L[j + m * l] * L[j + m * l];
@@ -1017,6 +1068,7 @@ __global__ __launch_bounds__(OD_BLOCK) void k_ilqr_backward_serial(IlqrArgs a) {
       L[j + m * j] = d;
       for (int i = j + 1; i < m; ++i) { double s = L[i + m * j]; for (int l = 0; l < j; ++l) s -= L[i + m * l] * L[j + m * l]; L[i + m * j] = s / d; }
     }
+    if (a.retry && !ok) break;
     // K = -(Quu+reg)^{-1} Qux (column by column), k = -(Quu+reg)^{-1} Qu
     for (int c = 0; c <= n; ++c) {
       double y[OD_IL_M];
@@ -1025,8 +1077,8 @@ __global__ __launch_bounds__(OD_BLOCK) void k_ilqr_backward_serial(IlqrArgs a) {
       for (int i = m - 1; i >= 0; --i) { double s = y[i]; for (int l = i + 1; l < m; ++l) s -= L[l + m * i] * y[l]; y[i] = s / L[i + m * i]; }
       for (int i = 0; i < m; ++i) { if (c < n) Kt[i + m * c] = -y[i]; else kt[i] = -y[i]; }
     }
-    for (int i = 0; i < m * n; ++i) a.K.at(i, kk) = Kt[i];
-    for (int i = 0; i < m; ++i) a.k.at(i, kk) = kt[i];
+    for (int i = 0; i < m * n; ++i) a.K.at(i, kk) = (TA)Kt[i];
+    for (int i = 0; i < m; ++i) a.k.at(i, kk) = (TA)kt[i];
     for (int i = 0; i < m; ++i) { dV1 += kt[i] * Qu[i]; double s = 0; for (int l = 0; l < m; ++l) s += Quu[i + m * l] * kt[l]; dV2 += 0.5 * kt[i] * s; }
     // value function update (Quu without reg, as in the cost-to-go expansion)
     double Quuk[OD_IL_M];
@@ -1044,6 +1096,17 @@ __global__ __launch_bounds__(OD_BLOCK) void k_ilqr_backward_serial(IlqrArgs a) {
       Vxx[i + n * j] = s;
     }
     for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) { const double s = 0.5 * (Vxx[i + n * j] + Vxx[j + n * i]); Vxx[i + n * j] = s; Vxx[j + n * i] = s; }
+  }
+  if (!a.retry || ok || !(reg < 1e6)) break;
+  reg = od_il_next_reg(reg);
+  }
+  if (a.retry && !ok) {
+    dV1 = 0.0; dV2 = 0.0;
+    for (int t = 0; t < a.T; ++t) {
+      const long kk = (long)t * a.B + b;
+      for (int i = 0; i < m * n; ++i) a.K.at(i, kk) = TA(0);
+      for (int i = 0; i < m; ++i) a.k.at(i, kk) = TA(0);
+    }
   }
   a.dV.at(0, b) = dV1;
   a.dV.at(1, b) = dV2;
@@ -1180,11 +1243,12 @@ int run_grad_pass(od_handle_s* h, StepArgs<double> g, long K, View<const double>
 }
 
 int run_step(od_handle_s* h, const char* fn, long B, const void* x, const void* u, void* d, void* dx, void* du,
-             void* dq3, int* status, int* iters, int want_grad, void* q3 = nullptr) {
+             void* dq3, int* status, int* iters, int want_grad, void* q3 = nullptr, long x_se = 0) {
   if (int rc = check_mech(h, fn)) return rc;
   if (B <= 0) return OD_OK;
   if (!x || (h->vt->nu > 0 && !u)) return fail(OD_ERR_INVALID, std::string(fn) + ": null input");
   StepArgs<double> a = step_args(h, B, B, x, u, d, dx, du, dq3, status, iters, want_grad);
+  if (x_se) a.x.se = x_se;         // (the states are the first B slots of a longer batch-minor array: od_ilqr_solver.inc)
   a.q3 = mkview<double>(q3, h->vt->nq, B, h->layout);
   if (!want_grad) {
     OD_HIP(h->vt->step_state(a, cfg_of(h, B), h->stream));
@@ -1234,6 +1298,7 @@ template <class T> static int rocket_impl(od_handle h, long B, int project, cons
   a.du = mkview<T>(du, 36, B, L);
   a.uproj = mkview<T>(uproj, 3, B, L);
   a.status = mkview<int>(status, 1, B, L);
+  a.skip = nullptr; a.live = nullptr; a.live_mod = 1;
   hipError_t e;
   if constexpr (sizeof(T) == 8) e = launch_rocket64(a, ppw_of(h, B), h->stream);
   else e = launch_rocket32(a, ppw_of(h, B), h->stream);
@@ -1255,6 +1320,7 @@ template <class T> static RocketArgs<T> rocket_args(od_handle h, long B, int pro
   a.project = project;
   a.want_grad = want_grad;
   a.x.p = nullptr; a.u.p = nullptr; a.y.p = nullptr; a.dx.p = nullptr; a.du.p = nullptr; a.uproj.p = nullptr; a.status.p = nullptr;
+  a.skip = nullptr; a.live = nullptr; a.live_mod = 1;
   return a;
 }
 
@@ -1574,6 +1640,7 @@ int od_rollout_policy(od_handle h, long B, int T, int nalpha, const void* alphas
   pa.K = mkcview<double>(K, nu * n, Kn, L);
   pa.kff = mkcview<double>(kff, nu, Kn, L);
   pa.U = mkview<double>(U, nu, Kc, L);
+  pa.skip = nullptr;
   OD_HIP(h->vt->rollout_policy(pa, cfg_of(h, P), h->stream));
   return OD_OK;
 }
@@ -1596,6 +1663,7 @@ int od_ilqr_backward(od_handle h, long B, int T, int n, int m, const void* A, co
   a.VxxT = mkcview<double>(VxxT, n * n, B, L); a.VxT = mkcview<double>(VxT, n, B, L);
   a.K = mkview<double>(K, m * n, Kn, L); a.k = mkview<double>(k, m, Kn, L);
   a.dV = mkview<double>(dV, 2, B, L); a.status = mkview<int>(status, 1, B, L);
+  a.reg_dev = nullptr; a.retry = 0; a.skip = nullptr;
 #if defined(__HIPCC__)
   {
     // batch-minor data: TB consecutive trajectories per workgroup (coalesced), as many as 64 KB of LDS hold; batch-major data
@@ -1628,12 +1696,12 @@ int od_ilqr_backward(od_handle h, long B, int T, int n, int m, const void* A, co
     if (tb == 8) OD_IL_SIZES(8);
     else if (tb == 4) OD_IL_SIZES(4);
     else if (tb == 2) OD_IL_SIZES(2);
-    else hipLaunchKernelGGL(k_ilqr_backward, dim3((unsigned)B), dim3(OD_IL_THREADS), 0, h->stream, a);
+    else hipLaunchKernelGGL((k_ilqr_backward<double>), dim3((unsigned)B), dim3(OD_IL_THREADS), 0, h->stream, a);
 #undef OD_IL_SIZES
 #undef OD_IL_LAUNCH
   }
 #else
-  hipLaunchKernelGGL(k_ilqr_backward_serial, od_grid(B, OD_BLOCK), dim3(OD_BLOCK), 0, h->stream, a);
+  hipLaunchKernelGGL((k_ilqr_backward_serial<double>), od_grid(B, OD_BLOCK), dim3(OD_BLOCK), 0, h->stream, a);
 #endif
   OD_HIP(hipGetLastError());
   return OD_OK;
@@ -1647,10 +1715,14 @@ template <class T> struct QuadCostArgs {
   View<const T> X, U;
   const double *Q, *R, *QT, *xref;
   double* J;
+  const int* skip;     // device flag (may be null): non-zero = the launch does nothing
+  const int* kstat;    // (may be null) status per knot (T * P): okall[p] = 1 iff bit 0 is set on every knot of trajectory p --
+  int* okall;          // "every solve of this rollout converged", what the Armijo selection of the iLQR iteration asks
 };
 // 64 consecutive trajectories per workgroup; its four wavefronts take the knots t = w, w + 4, ... and their partial sums are added
 // in a fixed order (the cost decides the Armijo test: it must not depend on scheduling).  N, M: compile-time sizes (0: any)
 template <class T, int N, int M> __global__ __launch_bounds__(256) void k_quad_cost(QuadCostArgs<T> a) {
+  if (a.skip && *a.skip) return;
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long p = (long)blockIdx.x * 64 + l;
   const long pp = p < a.P ? p : a.P - 1;
@@ -1664,10 +1736,12 @@ template <class T, int N, int M> __global__ __launch_bounds__(256) void k_quad_c
   if (w != 0) return;
   const int w0 = 0, w1 = 4;
 #endif
+  int okk = 1;
   for (int wq = w0; wq < w1; ++wq) {
   double J = 0.0;
   for (int t = wq; t <= a.Tn; t += 4) {
     const long ks = (long)t * a.P + pp;
+    if (a.kstat && t < a.Tn) okk &= a.kstat[ks];
     double v[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = i < n ? (double)a.X.at(i, ks) - a.xref[i] : 0.0;
@@ -1699,8 +1773,12 @@ template <class T, int N, int M> __global__ __launch_bounds__(256) void k_quad_c
   part[wq][l] = J;
   }
 #if defined(__HIPCC__)
+  __shared__ int okp[4][64];
+  okp[w][l] = okk;
   __syncthreads();
+  if (w == 0) okk = okp[0][l] & okp[1][l] & okp[2][l] & okp[3][l];
 #endif
+  if (w == 0 && p < a.P && a.okall) a.okall[p] = okk & 1;
   if (w == 0 && p < a.P) a.J[p] = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
 }
 }  // namespace
@@ -1724,10 +1802,10 @@ int od_quad_cost(od_handle h, long P, int T, int n, int m, int dtype, const void
     else OD_QC_LAUNCH(T_, 0, 0);                                                                          \
   } while (0)
   if (dtype == OD_F64) {
-    QuadCostArgs<double> a{P, T, n, m, mkcview<double>(X, n, (long)(T + 1) * P, L), mkcview<double>(U, m, (long)T * P, L), Q, R, QT, xref, J};
+    QuadCostArgs<double> a{P, T, n, m, mkcview<double>(X, n, (long)(T + 1) * P, L), mkcview<double>(U, m, (long)T * P, L), Q, R, QT, xref, J, nullptr, nullptr, nullptr};
     OD_QC_SIZES(double);
   } else {
-    QuadCostArgs<float> a{P, T, n, m, mkcview<float>(X, n, (long)(T + 1) * P, L), mkcview<float>(U, m, (long)T * P, L), Q, R, QT, xref, J};
+    QuadCostArgs<float> a{P, T, n, m, mkcview<float>(X, n, (long)(T + 1) * P, L), mkcview<float>(U, m, (long)T * P, L), Q, R, QT, xref, J, nullptr, nullptr, nullptr};
     OD_QC_SIZES(float);
   }
 #undef OD_QC_SIZES
@@ -2041,3 +2119,6 @@ int od_bundle_grad_host(od_handle h, int N, const double* x, const double* u, co
 }
 
 }  // extern "C"
+
+#include <vector>
+#include "od_ilqr_solver.inc"

@@ -8,8 +8,9 @@
 namespace od {
 
 template <class T> __global__ __launch_bounds__(OD_BLOCK) void k_rocket(RocketArgs<T> a, LaneMap lm) {
+  if (a.skip && *a.skip) return;
   const long b = lm.problem(blockIdx.x, threadIdx.x);
-  if (lm.active(threadIdx.x) && b < a.B) unit_rocket<Model_rocket_dynamics, Model_rocket_projection, T>(a, b);
+  if (lm.active(threadIdx.x) && b < a.B && (!a.live || a.live[b % a.live_mod])) unit_rocket<Model_rocket_dynamics, Model_rocket_projection, T>(a, b);
 }
 
 hipError_t launch_rocket64(const RocketArgs<double>& a, int ppw, hipStream_t s) {
@@ -35,6 +36,7 @@ hipError_t launch_soc_project32(const RocketArgs<float>& a, int ppw, hipStream_t
 }
 
 template <class T> __global__ __launch_bounds__(OD_BLOCK) void k_rocket_rollout(RocketRolloutArgs<T> a, LaneMap lm) {
+  if (a.a.skip && *a.a.skip) return;
   const long p = lm.problem(blockIdx.x, threadIdx.x);
   if (lm.active(threadIdx.x) && p < a.a.B) unit_rocket_rollout<Model_rocket_dynamics, Model_rocket_projection, T>(a, p);
 }

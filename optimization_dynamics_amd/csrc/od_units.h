@@ -234,6 +234,7 @@ template <class T> struct PolicyArgs {
   View<const T> K;       // nu x 2nq col-major per nominal knot
   View<const T> kff;     // nu per nominal knot
   View<T> U;             // nu per candidate knot: controls actually applied
+  const int* skip;       // device flag (may be null): non-zero = the launch does nothing (device-resident iLQR iteration, od_ilqr_solver.inc)
 };
 
 template <class M, class T> OD_HD void unit_rollout_policy(const PolicyArgs<T>& pa, long p) {
@@ -433,6 +434,10 @@ template <class T> struct RocketArgs {
   View<T> du;         // 12 x 3  col-major       (fu_*; projected: dz_dyn[:,u] * dproj[1:3,1:3])
   View<T> uproj;      // 3 (projected control; optional)
   View<int> status;   // bit0/1 dyn eval/grad ok, bit4/5 projection eval/grad ok
+  // device-resident iLQR iteration (od_ilqr_solver.inc); all null otherwise
+  const int* skip;    // non-zero = the launch does nothing
+  const int* live;    // per trajectory: knot b belongs to trajectory b % live_mod and is computed only if live[b % live_mod] != 0
+  long live_mod;
 };
 
 // d(projected u)/du: 3 x 3 col-major kept in registers (column index is dynamic -> selects)

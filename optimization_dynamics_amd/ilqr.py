@@ -31,33 +31,36 @@ class QuadraticObjective:
         self.goal_idx = None if goal_idx is None else torch.as_tensor(np.asarray(goal_idx), device=dev, dtype=torch.long)
         self.goal = None if goal is None else as_t(goal)
         self.device = dev
+        self._host = {id(M): np.asarray(h, dtype=np.float64) for M, h in ((self.Q, Q), (self.R, R), (self.QT, QT))}   # (no device read-back in `expansion`)
 
     def constraint(self, X):
         """c = x_T[idx] - goal, shape (nc, P)"""
         return X[self.goal_idx, -1, :] - self.goal[:, None]
 
-    def bind(self, im):
-        """use the library's one-pass cost kernel (od_quad_cost) through this dynamics object's handle"""
-        self._im = im
-        self._cm = tuple(M.T.contiguous() for M in (self.Q, self.R, self.QT))       # column-major flattenings
+    def _column_major(self):
+        if getattr(self, "_cm", None) is None:
+            self._cm = tuple(M.T.contiguous() for M in (self.Q, self.R, self.QT))       # column-major flattenings
+        return self._cm
 
-    def _value_kernel(self, X, U):
+    def _value_kernel(self, im, X, U):
+        """the library's one-pass cost kernel (od_quad_cost) through the dynamics object `im`'s handle"""
         from ._lib import OD_F32, OD_F64
-        im = self._im
         X, U = X.contiguous(), U.contiguous()
         T, P = U.shape[1], U.shape[2]
         J = torch.empty(P, dtype=torch.float64, device=X.device)
+        cm = self._column_major()
         im._use_current_stream()
         im.lib.check(im.lib.cdll.od_quad_cost(im._h, P, T, self.n, self.m, OD_F32 if X.dtype == torch.float32 else OD_F64, _ptr(X), _ptr(U),
-                                              _ptr(self._cm[0]), _ptr(self._cm[1]), _ptr(self._cm[2]), _ptr(self.x_ref), _ptr(J)))
+                                              _ptr(cm[0]), _ptr(cm[1]), _ptr(cm[2]), _ptr(self.x_ref), _ptr(J)))
         return J
 
-    def value(self, X, U, lam=None, rho=0.0):
-        """X: (n, T+1, P), U: (m, T, P) -> cost per trajectory (P,)"""
+    def value(self, X, U, lam=None, rho=0.0, im=None):
+        """X: (n, T+1, P), U: (m, T, P) -> cost per trajectory (P,).  im: a dynamics object whose handle runs the cost kernel
+        (batch-minor layout, live handle); without it, or where the kernel does not apply, the same formula in torch"""
         T, P = U.shape[1], U.shape[2]
-        if getattr(self, "_im", None) is not None and X.dtype == U.dtype and X.dtype in (torch.float32, torch.float64) \
-                and X.device == self.x_ref.device and self.n <= 16 and self.m <= 12:
-            J = self._value_kernel(X, U)
+        if im is not None and getattr(im, "_h", None) and getattr(im, "layout", 0) == 0 and X.dtype == U.dtype \
+                and X.dtype in (torch.float32, torch.float64) and X.device == self.x_ref.device and self.n <= 16 and self.m <= 12:
+            J = self._value_kernel(im, X, U)
         else:
             dx = X.double() - self.x_ref[:, None, None]
 
@@ -76,13 +79,22 @@ class QuadraticObjective:
         n, m = self.n, self.m
         T, P = U.shape[1], U.shape[2]
         dx = X - self.x_ref[:, None, None]
-        lx = torch.einsum("ij,jtp->itp", self.Q, dx[:, :-1]).contiguous()
-        lu = torch.einsum("ij,jtp->itp", self.R, U).contiguous()
+
+        def matvec(M, v):       # sum_j M[i, j] v[j] accumulated in the order j = 0, 1, ... (the order of k_il_expand, od_ilqr_solver.inc)
+            out = torch.zeros((M.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+            Mh = self._host[id(M)]
+            for i in range(M.shape[0]):
+                for j in range(M.shape[1]):
+                    out[i] = out[i] + float(Mh[i, j]) * v[j]
+            return out
+
+        lx = matvec(self.Q, dx[:, :-1]).contiguous()
+        lu = matvec(self.R, U).contiguous()
         lxx = self.Q.T.reshape(n * n, 1, 1).expand(n * n, T, P).contiguous()
         luu = self.R.T.reshape(m * m, 1, 1).expand(m * m, T, P).contiguous()
         lux = torch.zeros(m * n, T, P, dtype=torch.float64, device=X.device)
         Vxx = self.QT.clone()[:, :, None].repeat(1, 1, P)
-        Vx = torch.einsum("ij,jp->ip", self.QT, dx[:, -1])
+        Vx = matvec(self.QT, dx[:, -1])
         if self.goal_idx is not None and lam is not None:
             c = self.constraint(X)
             Vx[self.goal_idx] += lam + rho * c
@@ -104,8 +116,7 @@ class ILQR:
             self.n, self.m = im.n, im.m
         self.alphas = torch.tensor(alphas, dtype=torch.float64, device=im.device)
         self.reg, self.c1 = reg, c1
-        if hasattr(objective, "bind"):
-            objective.bind(im)
+        self._dev = None
 
     # -- the three device steps ----------------------------------------------------------------
     def linearize(self, x1, U):
@@ -119,9 +130,12 @@ class ILQR:
         B = U.shape[-1]
         Xk, Uk = X[:, :-1].reshape(n, T * B), U.reshape(m, T * B)
         if isinstance(self.im, ImplicitDynamics):
-            _, DX, DU, _, _ = self.im.step_grad(Xk, Uk)
+            _, DX, DU, st, _ = self.im.step_grad(Xk, Uk)
+            self.last_linearisation_ok = ((st & 3) == 3).view(T, B)
         else:
-            DX, DU = self.im.linearize_knots(Xk, Uk)
+            DX, DU, st = self.im.linearize_knots(Xk, Uk, with_status=True)
+            need = 0x33 if self.im.project else 0x3
+            self.last_linearisation_ok = ((st & need) == need).view(T, B)
         return DX.unflatten(-1, (T, B)), DU.unflatten(-1, (T, B))
 
     def backward(self, A, Bm, quad, reg):
@@ -157,8 +171,34 @@ class ILQR:
         return Xc, Uc, st
 
     # -- solver --------------------------------------------------------------------------------
-    def solve(self, x1, U0, max_iter=50, max_al_iter=1, rho_init=1.0, rho_scale=10.0, con_tol=1e-3, obj_tol=1e-6, verbose=False,
-              reuse_forward_states=True):
+    # -- the iteration on the device (od_ilqr_*): what `solve` runs --------------------------------------------------
+    def device_solver(self, B, max_iter=50, max_al_iter=1, rho_init=1.0, rho_scale=10.0, con_tol=1e-3, obj_tol=1e-6, history=0):
+        """an od_ilqr solver object for B problems with this objective (buffers allocated once; see DeviceILQR)"""
+        return DeviceILQR(self, B, max_iter=max_iter, max_al_iter=max_al_iter, rho_init=rho_init, rho_scale=rho_scale,
+                          con_tol=con_tol, obj_tol=obj_tol, history=history)
+
+    def solve(self, x1, U0, max_iter=50, max_al_iter=1, rho_init=1.0, rho_scale=10.0, con_tol=1e-3, obj_tol=1e-6, verbose=False):
+        """iLQR.solve!: every iteration runs on the device behind the C ABI (od_ilqr_solve), no host round trip per iteration.
+        -> X (n, T+1, B), U (m, T, B), J (B,), history (list of (B,) costs, one per iteration)"""
+        x1 = self.im._prep(x1)
+        U0 = self.im._prep(U0)
+        key = (x1.shape[-1], max_iter, max_al_iter, rho_init, rho_scale, con_tol, obj_tol)
+        if self._dev is None or self._dev.key != key:
+            self._dev = self.device_solver(x1.shape[-1], max_iter, max_al_iter, rho_init, rho_scale, con_tol, obj_tol)
+            self._dev.key = key
+        d = self._dev
+        d.solve(x1, U0)
+        X, U, J = d.get()
+        hist = d.history()
+        if verbose:
+            i = d.info()
+            print("od_ilqr_solve: %d iterations, %d multiplier updates, max dJ %.3g, max violation %.3g, reg %.3g" %
+                  (i.iterations, i.al_iterations, i.max_dJ, i.max_violation, i.reg))
+        return X, U, J, [h for h in hist]
+
+    # -- the same loop composed from the separate entry points, decisions on the host (the checker of `solve`) -------
+    def solve_stepwise(self, x1, U0, max_iter=50, max_al_iter=1, rho_init=1.0, rho_scale=10.0, con_tol=1e-3, obj_tol=1e-6, verbose=False,
+                       reuse_forward_states=True):
         """reuse_forward_states: the accepted candidate of the forward pass IS the new nominal trajectory (its states were
         computed by the same time recursion), so the iteration linearises on those states knot by knot instead of rolling the
         trajectory out a second time (False: the second rollout, as a check)"""
@@ -174,8 +214,8 @@ class ILQR:
         history = []
         X, A, Bm, st = self.linearize(x1, U)
         for al in range(max_al_iter):
-            J = obj.value(X, U, lam, rho)
-            reg = torch.full((1,), self.reg).item()
+            J = obj.value(X, U, lam, rho, im=im)
+            reg = float(self.reg)
             for it in range(max_iter):
                 quad = obj.expansion(X, U, lam, rho)
                 K, k, dV, bst = self.backward(A, Bm, quad, reg)
@@ -195,10 +235,11 @@ class ILQR:
                 if bad.any():        # still not factorisable (non-finite data): no step for these, the line search rejects them
                     K[..., bad] = 0.0; k[..., bad] = 0.0; dV[:, bad] = 0.0
                 Xc, Uc, cst = self.forward(x1, X, U, K, k)
-                Jc = obj.value(Xc, Uc, None if lam is None else lam.repeat(1, na), rho).view(na, B)
+                Jc = obj.value(Xc, Uc, None if lam is None else lam.repeat(1, na), rho, im=im).view(na, B)
                 ok_roll = ((cst & 1) == 1).all(0).view(na, B)
                 expected = self.alphas[:, None] * dV[0][None, :] + self.alphas[:, None] ** 2 * dV[1][None, :]
-                accept = ok_roll & torch.isfinite(Jc) & (Jc <= J[None, :] + self.c1 * expected)
+                # (a zeroed trajectory reproduces its nominal: Jc == J and expected == 0 would pass the Armijo test -- it has no step)
+                accept = ok_roll & torch.isfinite(Jc) & (Jc <= J[None, :] + self.c1 * expected) & ~bad[None, :]
                 first = torch.where(accept.any(0), accept.float().argmax(0), torch.full((B,), -1, device=im.device, dtype=torch.long))
                 took = first >= 0
                 sel = torch.clamp(first, min=0) * B + torch.arange(B, device=im.device)
@@ -212,7 +253,7 @@ class ILQR:
                         J = Jn
                     else:
                         X, A, Bm, st = self.linearize(x1, U)
-                        J = obj.value(X, U, lam, rho)
+                        J = obj.value(X, U, lam, rho, im=im)
                 history.append(J.clone())
                 if verbose:
                     print("al %d it %d  J mean %.6g  accepted %d/%d  max dJ %.3g" % (al, it, J.mean().item(), int(took.sum()), B, dJ.max().item()))
@@ -232,3 +273,95 @@ class ILQR:
             lam = lam + rho * c
             rho = rho * rho_scale
         return X, U, J, history
+
+
+class DeviceILQR:
+    """od_ilqr_* (include/od_mi355x.h): the whole iLQR iteration on the device, decisions included.  `iterate(n)` only enqueues
+    kernels on the current stream (capturable in a HIP graph); `solve` is od_ilqr_solve."""
+
+    def __init__(self, ilqr: ILQR, B, max_iter=50, max_al_iter=1, rho_init=1.0, rho_scale=10.0, con_tol=1e-3, obj_tol=1e-6, history=0):
+        import ctypes as C
+        from . import _lib
+        im, obj = ilqr.im, ilqr.obj
+        self.im, self.lib, self.B, self.T, self.n, self.m = im, im.lib, int(B), ilqr.T, ilqr.n, ilqr.m
+        o = _lib.IlqrOptions()
+        self.lib.check(self.lib.cdll.od_ilqr_default_options(C.byref(o)))
+        o.reg, o.c1, o.obj_tol, o.con_tol = float(ilqr.reg), float(ilqr.c1), float(obj_tol), float(con_tol)
+        o.rho_init, o.rho_scale, o.max_iter, o.max_al_iter = float(rho_init), float(rho_scale), int(max_iter), int(max_al_iter)
+        o.project = 1 if getattr(im, "project", True) else 0
+        o.history = int(history)
+        self.options = o
+        al = np.ascontiguousarray(ilqr.alphas.cpu().numpy(), dtype=np.float64)
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        h = C.c_void_p()
+        im._use_current_stream()
+        self.lib.check(self.lib.cdll.od_ilqr_create(im._h, self.B, self.T, al.size, dp(al), C.byref(o), C.byref(h)))
+        self._s = h
+        f = lambda t: np.ascontiguousarray(t.cpu().numpy(), dtype=np.float64)
+        Q, R, QT, xr = f(obj.Q.T), f(obj.R.T), f(obj.QT.T), f(obj.x_ref)            # column-major flattenings
+        if obj.goal_idx is not None:
+            gi = np.ascontiguousarray(obj.goal_idx.cpu().numpy(), dtype=np.int32)
+            g = f(obj.goal)
+            self.lib.check(self.lib.cdll.od_ilqr_set_objective(self._s, dp(Q), dp(R), dp(QT), dp(xr), gi.size, gi.ctypes.data_as(C.POINTER(C.c_int)), dp(g)))
+        else:
+            self.lib.check(self.lib.cdll.od_ilqr_set_objective(self._s, dp(Q), dp(R), dp(QT), dp(xr), 0, None, None))
+        self.max_hist = history if history > 0 else max_iter * max_al_iter
+
+    def __del__(self):
+        try:
+            if getattr(self, "_s", None) and getattr(self.im, "_h", None):
+                self.lib.cdll.od_ilqr_destroy(self._s)
+            self._s = None
+        except Exception:
+            pass
+
+    def _args(self, x1, U0):
+        x1 = self.im._prep(x1)
+        U0 = self.im._prep(U0)
+        assert x1.shape == (self.n, self.B) and U0.shape == (self.m, self.T, self.B)
+        self.im._use_current_stream()
+        return x1, U0
+
+    def init(self, x1, U0):
+        x1, U0 = self._args(x1, U0)
+        self.lib.check(self.lib.cdll.od_ilqr_init(self._s, _ptr(x1), _ptr(U0)))
+
+    def iterate(self, n=1):
+        self.im._use_current_stream()
+        self.lib.check(self.lib.cdll.od_ilqr_iterate(self._s, int(n)))
+
+    def al_update(self):
+        self.im._use_current_stream()
+        self.lib.check(self.lib.cdll.od_ilqr_al_update(self._s))
+
+    def solve(self, x1, U0):
+        x1, U0 = self._args(x1, U0)
+        self.lib.check(self.lib.cdll.od_ilqr_solve(self._s, _ptr(x1), _ptr(U0)))
+
+    def get(self, gains=False):
+        dev = self.im.device
+        X = torch.empty(self.n, self.T + 1, self.B, dtype=torch.float64, device=dev)
+        U = torch.empty(self.m, self.T, self.B, dtype=torch.float64, device=dev)
+        J = torch.empty(self.B, dtype=torch.float64, device=dev)
+        K = torch.empty(self.m * self.n, self.T, self.B, dtype=torch.float64, device=dev) if gains else None
+        k = torch.empty(self.m, self.T, self.B, dtype=torch.float64, device=dev) if gains else None
+        self.im._use_current_stream()
+        self.lib.check(self.lib.cdll.od_ilqr_get(self._s, _ptr(X), _ptr(U), _ptr(J), _ptr(K) if gains else None, _ptr(k) if gains else None))
+        return (X, U, J, K, k) if gains else (X, U, J)
+
+    def info(self):
+        import ctypes as C
+        from . import _lib
+        i = _lib.IlqrInfo()
+        self.im._use_current_stream()
+        self.lib.check(self.lib.cdll.od_ilqr_get_info(self._s, C.byref(i)))
+        return i
+
+    def history(self):
+        """(iterations, B): the costs after every iteration since init"""
+        H = torch.empty(self.max_hist, self.B, dtype=torch.float64, device=self.im.device)
+        self.im._use_current_stream()
+        rows = self.lib.cdll.od_ilqr_get_history(self._s, _ptr(H), self.max_hist)
+        if rows < 0:
+            self.lib.check(rows)
+        return H[:rows]

@@ -118,8 +118,12 @@ class RocketDynamics:
     def __init__(self, info, project=True):
         self.info, self.project = info, project
         self.n, self.m = 12, 3
-        self.device, self.lib, self._h = info.device, info.lib, info._h
+        self.device, self.lib = info.device, info.lib
         self._use_current_stream = info._use_current_stream
+
+    @property
+    def _h(self):
+        return self.info._h          # (None once the RocketInfo is closed)
 
     def _prep(self, t):
         return t.to(device=self.device, dtype=torch.float64).contiguous()
@@ -134,10 +138,10 @@ class RocketDynamics:
             Bm = DU.reshape(12, 3, T, B).double()
         return X.double(), A, Bm, st, None, None
 
-    def linearize_knots(self, Xk, Uk):
+    def linearize_knots(self, Xk, Uk, with_status=False):
         """fx / fu (projection chain rule included) on independent knots: Xk (12, K), Uk (3, K) -> (12, 12, K), (12, 3, K)"""
-        _, DX, DU, _, _ = self.info.solve(Xk, Uk, project=self.project, grads=True)
-        return DX.double(), DU.double()
+        _, DX, DU, _, st = self.info.solve(Xk, Uk, project=self.project, grads=True)
+        return (DX.double(), DU.double(), st) if with_status else (DX.double(), DU.double())
 
     def rollout_policy(self, x1, X, U, K, k, alphas):
         Xc, Uc, st = _rocket_rollout(self.info, x1, U, self.project, policy=(alphas, X, K, k))

@@ -153,11 +153,10 @@ def check_quad_cost(lib, device):
         sym = lambda k: (lambda G: G @ G.T + np.eye(k))(rng.normal(size=(k, k)))
         obj = IL.QuadraticObjective(sym(n), sym(m), sym(n), rng.normal(size=n), device=device)
         X = torch.tensor(rng.normal(size=(n, T + 1, Pn)), device=device); U = torch.tensor(rng.normal(size=(m, T, Pn)), device=device)
-        ref = obj.value(X, U)                                   # (not bound: the torch formula)
-        obj.bind(im)
-        got = obj.value(X, U)
+        ref = obj.value(X, U)                                   # (no handle: the torch formula)
+        got = obj.value(X, U, im=im)
         assert ((got - ref).abs() <= 1e-12 * ref.abs().clamp(min=1.0)).all()
-        got32 = obj.value(X.float(), U.float())
+        got32 = obj.value(X.float(), U.float(), im=im)
         ref32 = IL.QuadraticObjective(obj.Q.cpu().numpy(), obj.R.cpu().numpy(), obj.QT.cpu().numpy(), obj.x_ref.cpu().numpy(), device=device).value(X.float().double(), U.float().double())
         assert ((got32 - ref32).abs() <= 1e-12 * ref32.abs().clamp(min=1.0)).all()
 
@@ -167,8 +166,8 @@ def check_reused_forward_states(lib, device, B=8, T=25):
     out a second time (reuse_forward_states=False) must give the same optimisation: costs equal to rounding, iteration by iteration"""
     im, obj, x1, U0 = cartpole_problem(lib, device, B, T, seed=1)
     x1t, Ut = torch.tensor(x1, device=device), torch.tensor(U0, device=device)
-    a = IL.ILQR(im, obj, T).solve(x1t, Ut, max_iter=10, max_al_iter=1)
-    b = IL.ILQR(im, obj, T).solve(x1t, Ut, max_iter=10, max_al_iter=1, reuse_forward_states=False)
+    a = IL.ILQR(im, obj, T).solve_stepwise(x1t, Ut, max_iter=10, max_al_iter=1)
+    b = IL.ILQR(im, obj, T).solve_stepwise(x1t, Ut, max_iter=10, max_al_iter=1, reuse_forward_states=False)
     assert len(a[3]) == len(b[3])
     for ja, jb in zip(a[3], b[3]):
         assert ((ja - jb).abs() <= 1e-9 * jb.abs().clamp(min=1.0)).all()
@@ -207,23 +206,165 @@ def rocket_problem(lib, device, B, T, dtype=torch.float64, seed=0):
     return dyn, obj, x1, U0
 
 
+def check_rollout_against_oracle(oracle, dyn, x1, U0, X, A, Bm, dtype, ntraj=2, h=0.05, u_max=12.5):
+    """a projected rocket rollout of the device (X, and its linearisation A, Bm) against the oracle, in the handle's precision:
+      * chained: the oracle's f_rocket_proj from x1 along the same controls -- the projected control is only kappa_tol = 1e-4
+        accurate by construction and its line search has rounding-level ties (parity_checks.check_rocket), so chained states
+        agree to that level (1e-3) in either precision;
+      * knot by knot, no path dependence left: f_rocket_proj / fx of the device on its own rollout states (independent knots, the
+        solve the linearisation comes from) against the oracle's dynamics step from the same state with the control the DEVICE
+        projected to -- at the bars (1e-6 / 1e-4 double, 5e-4 / 2e-2 single)"""
+    T = U0.shape[1]
+    tolS, tolG = (1e-6, 1e-4) if dtype == torch.float64 else (5e-4, 2e-2)
+    Xn, An = X.double().cpu().numpy(), A.double().cpu().numpy()
+    for b in range(ntraj):
+        x = x1[:, b].copy()
+        for t in range(T):
+            ok, x, dx, du = oracle.rocket_proj(h, u_max, x, U0[:, t, b])
+            assert np.abs(Xn[:, t + 1, b] - x).max() < 1e-3 * max(1, np.abs(x).max()), (b, t)
+        assert np.abs(An[:, :, T - 1, b] - dx).max() < 2e-2 * max(1, np.abs(dx).max())
+        Xk, Uk = torch.tensor(Xn[:, :T, b]), torch.tensor(U0[:, :, b])
+        Y, DX, DU, UP, st = dyn.info.solve(Xk, Uk, project=True, grads=True)
+        Y, DX, UP, st = Y.double().cpu().numpy(), DX.double().cpu().numpy(), UP.double().cpu().numpy(), st.cpu().numpy()
+        for t in range(T):
+            if (st[t] & 0x33) != 0x33:
+                continue
+            # (the rollout kernel and the independent-knot kernel are two compilations of the same solve: where their projections take
+            # different line-search paths they differ at the projection's kappa_tol level, like device and oracle do)
+            assert np.abs(Y[:, t] - Xn[:, t + 1, b]).max() <= 1e-3 * max(1, np.abs(Y[:, t]).max()), (b, t)
+            ok, y, dz, it = oracle.rocket(h, Xn[:, t, b], UP[:, t], True)
+            assert np.abs(Y[:, t] - y).max() < tolS * max(1, np.abs(y).max()), (b, t, np.abs(Y[:, t] - y).max())
+            assert np.abs(DX[:, :, t] - dz[:, :12]).max() < tolG * max(1, np.abs(dz[:, :12]).max()), (b, t)
+            assert np.abs(DX[:, :, t] - An[:, :, t, b]).max() <= 1e-6 * max(1, np.abs(DX[:, :, t]).max())      # the linearisation IS that solve
+
+
 def check_rocket_ilqr(oracle, lib, device, B=4, T=20, dtype=torch.float64):
     dyn, obj, x1, U0 = rocket_problem(lib, device, B, T, dtype=dtype)
     x1t, Ut = torch.tensor(x1, device=device), torch.tensor(U0, device=device)
-    # rollout == chained f_rocket_proj of the oracle
+    # rollout == chained f_rocket_proj of the oracle, in either precision
     X, A, Bm, st, _, _ = dyn.rollout(x1t, Ut)
-    if dtype == torch.float64:
-        for b in range(min(B, 2)):
-            x = x1[:, b].copy()
-            for t in range(T):
-                ok, x, dx, du = oracle.rocket_proj(0.05, 12.5, x, U0[:, t, b])
-                # the projected control is only kappa_tol = 1e-4 accurate by construction and its line search has
-                # rounding-level ties (parity_checks.check_rocket): the chained states agree to that level
-                assert np.abs(X[:, t + 1, b].cpu().numpy() - x).max() < 1e-3 * max(1, np.abs(x).max())
-            assert np.abs(A[:, :, T - 1, b].cpu().numpy() - dx).max() < 2e-2 * max(1, np.abs(dx).max())
+    check_rollout_against_oracle(oracle, dyn, x1, U0, X, A, Bm, dtype, ntraj=min(B, 2))
     solver = IL.ILQR(dyn, obj, T)
     J0 = obj.value(X, Ut.double())
     Xs, Us, J, hist = solver.solve(x1t, Ut, max_iter=10)
     Jf = obj.value(Xs, Us)
     assert torch.isfinite(Jf).all() and (Jf <= J0 + 1e-6).all() and (Jf < 0.8 * J0).float().mean().item() > 0.7
     return J0, Jf
+
+
+def config5_problem(lib, device, B, dtype=torch.float64, T=61, seed=1):
+    """BASELINE config 5 with the inputs of examples/rocket.jl, `:projection` mode: h = 0.05, T = 61 (60 steps), u_max = 12.5
+    (:16-20), x1 = [2.5, 2.5, 10, MRP(RotZ(pi/4) RotY(-pi/2)), 0, 0, -1, 0, 0, 0] (:44-50), xT = [0, 0, 1, MRP(RotZ(pi/4)), 0...]
+    (:52-55), the quadratic objective of :58-73 (stage weights h [0.1 x3, 1e-5 x3, 0.1 x3, 1000 x3] and h [1000, 1000, 100], terminal
+    h 1000 I), initial controls 1e-3 randn (:116-117; trajectory b draws with seed + b, so trajectory 0 is the example's).
+    The example's stage / terminal constraints are IterativeLQR's business and not part of the path."""
+    import math
+    from optimization_dynamics_amd import rocket as rk
+    sys_path_examples()
+    import rocket as ex
+    h, u_max = 0.05, 12.5
+    info = rk.RocketInfo(models.rocket, u_max, h, dtype=dtype, device=device, lib=lib)
+    dyn = rk.RocketDynamics(info, project=True)
+    x1 = np.zeros(12); x1[:3] = [2.5, 2.5, 10.0]
+    x1[3:6] = ex.mrp_of(ex.rot_z(0.25 * math.pi) @ ex.rot_y(-0.5 * math.pi)); x1[8] = -1.0
+    xT = np.zeros(12); xT[2] = 1.0
+    xT[3:6] = ex.mrp_of(ex.rot_z(0.25 * math.pi) @ ex.rot_y(0.0))
+    Q = np.diag(h * np.r_[1.0e-1 * np.ones(3), 1.0e-5 * np.ones(3), 1.0e-1 * np.ones(3), 1000.0 * np.ones(3)])
+    R = np.diag(h * np.array([1000.0, 1000.0, 100.0]))
+    QT = h * 1000.0 * np.eye(12)
+    obj = IL.QuadraticObjective(Q, R, QT, x_ref=xT, device=device)
+    U0 = np.stack([1.0e-3 * np.random.default_rng(seed + b).normal(size=(3, T - 1)) for b in range(B)], axis=-1)
+    return dyn, obj, np.repeat(x1[:, None], B, axis=1), U0
+
+
+def sys_path_examples():
+    import os, sys
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples")
+    if d not in sys.path:
+        sys.path.insert(0, d)
+
+
+def check_config5(oracle, lib, device, B=1024, iters=12):
+    """BASELINE config 5 as stated -- rocket thrust-cone SOCP step inside the full iLQR loop with implicit gradients, T = 61 --
+    in double and in single precision, against the oracle:
+      * the nominal rollout and its linearisation against the oracle's f_rocket_proj / fx (check_rollout_against_oracle);
+      * K, k, dV of od_ilqr_backward at (n, m) = (12, 3) on that linearisation against the numpy Riccati recursion;
+      * the iteration on the device (od_ilqr_solve) against the loop composed on the host, cost by cost;
+      * the single-precision cost history against the double-precision one."""
+    from oracle import ilqr_np
+    hist = {}
+    T = 60
+    for dtype in (torch.float64, torch.float32):
+        dyn, obj, x1, U0 = config5_problem(lib, device, B, dtype=dtype)
+        x1t, Ut = torch.tensor(x1, device=device), torch.tensor(U0, device=device)
+        X, A, Bm, st, _, _ = dyn.rollout(x1t, Ut)
+        need = 0x33
+        assert ((st & 1) == 1).double().mean().item() > 0.999
+        check_rollout_against_oracle(oracle, dyn, x1, U0, X, A, Bm, dtype, ntraj=2)
+        sol = IL.ILQR(dyn, obj, T)
+        quad = obj.expansion(X, Ut, None, 0.0)
+        K, k, dV, bst = sol.backward(A, Bm, quad, 1e-6)
+        assert (bst == 1).all()
+        lxx, luu, lux, lx, lu, VxxT, VxT = [q.cpu().numpy() for q in quad]
+        An, Bn, Kn, kn, dVn = A.cpu().numpy(), Bm.cpu().numpy(), K.cpu().numpy(), k.cpu().numpy(), dV.cpu().numpy()
+        n, m = 12, 3
+        for b in (0, B // 2, B - 1):
+            Kr, kr, dVr = ilqr_np.backward(
+                np.moveaxis(An[:, :, :, b], 2, 0), np.moveaxis(Bn[:, :, :, b], 2, 0),
+                np.moveaxis(lxx[:, :, b].reshape(n, n, T, order="F"), 2, 0), np.moveaxis(luu[:, :, b].reshape(m, m, T, order="F"), 2, 0),
+                np.moveaxis(lux[:, :, b].reshape(m, n, T, order="F"), 2, 0), lx[:, :, b].T, lu[:, :, b].T,
+                VxxT[:, b].reshape(n, n, order="F"), VxT[:, b], 1e-6)
+            Kd = np.moveaxis(Kn[:, :, b].reshape(m, n, T, order="F"), 2, 0)
+            assert np.abs(Kd - Kr).max() < 1e-8 * max(1.0, np.abs(Kr).max()), (dtype, b)
+            assert np.abs(kn[:, :, b].T - kr).max() < 1e-8 * max(1.0, np.abs(kr).max())
+            assert np.abs(dVn[:, b] - dVr).max() < 1e-8 * max(1.0, np.abs(dVr).max())
+        kw = dict(max_iter=iters, max_al_iter=1, obj_tol=0.0)
+        got = sol.solve(x1t, Ut, **kw)
+        ref = IL.ILQR(dyn, obj, T).solve_stepwise(x1t, Ut, **kw)
+        assert len(got[3]) == len(ref[3]) == iters
+        for i, (ja, jb) in enumerate(zip(got[3], ref[3])):
+            assert ((ja - jb).abs() <= 1e-9 * jb.abs().clamp(min=1.0)).all(), (dtype, i, (ja - jb).abs().max().item())
+        J0 = obj.value(X.double(), Ut)
+        assert torch.isfinite(got[2]).all() and (got[2] <= J0 + 1e-6).all() and (got[2] < 0.9 * J0).double().mean().item() > 0.9
+        assert sol._dev.info().bad_linearisations <= max(1, T * B // 2000)
+        hist[dtype] = torch.stack(got[3]).cpu().numpy()
+    # single against double precision: the same optimisation (accept decisions of single trajectories may differ, the batch does not)
+    h64, h32 = hist[torch.float64], hist[torch.float32]
+    rel = np.abs(h32.mean(1) - h64.mean(1)) / np.abs(h64.mean(1))
+    assert rel.max() < 2e-2, rel
+    assert np.median(np.abs(h32[0] - h64[0]) / np.abs(h64[0])) < 1e-3
+    return hist
+
+
+def check_device_iteration(lib, device, problem="cartpole", B=6, T=15, dtype=torch.float64, max_iter=8, max_al_iter=2, seed=1, tol=1e-9):
+    """od_ilqr_* (the whole iteration on the device, decisions included) against the same loop composed from the separate entry
+    points with the decisions on the host (ILQR.solve_stepwise): the same costs iteration by iteration, the same number of
+    iterations, the same trajectories.  The two differ in the summation order of the cost expansion only (a loop in k_il_expand, a
+    GEMM in torch), so costs agree to rounding, not bit for bit; single precision: the candidates' states are single-precision
+    numbers in both, the comparison is as tight."""
+    if problem == "cartpole":
+        im, obj, x1, U0 = cartpole_problem(lib, device, B, T, seed=seed)
+    else:
+        im, obj, x1, U0 = rocket_problem(lib, device, B, T, dtype=dtype, seed=seed)
+    x1t, Ut = torch.tensor(x1, device=device), torch.tensor(U0, device=device)
+    kw = dict(max_iter=max_iter, max_al_iter=max_al_iter, obj_tol=1e-7, con_tol=1e-4)
+    ref = IL.ILQR(im, obj, T).solve_stepwise(x1t, Ut, **kw)
+    sol = IL.ILQR(im, obj, T)
+    got = sol.solve(x1t, Ut, **kw)
+    info = sol._dev.info()
+    assert len(got[3]) == len(ref[3]) == info.iterations, (len(got[3]), len(ref[3]), info.iterations)
+    for i, (ja, jb) in enumerate(zip(got[3], ref[3])):
+        assert ((ja - jb).abs() <= tol * jb.abs().clamp(min=1.0)).all(), (i, (ja - jb).abs().max().item())
+    sc = lambda t: t.abs().max().clamp(min=1.0).item()
+    assert (got[0] - ref[0]).abs().max().item() < 1e3 * tol * sc(ref[0]) and (got[1] - ref[1]).abs().max().item() < 1e3 * tol * sc(ref[1])
+    assert ((got[2] - ref[2]).abs() <= tol * ref[2].abs().clamp(min=1.0)).all()
+    # the pieces separately: init + n x iterate(1) reproduces solve (no augmented-Lagrangian round)
+    d = sol.device_solver(B, max_iter=max_iter, max_al_iter=1, obj_tol=1e-7, con_tol=1e-4)
+    d.init(x1t, Ut)
+    d.iterate(3)
+    d.iterate(2)
+    h5 = d.history()
+    assert h5.shape[0] == min(5, d.info().iterations)
+    for i in range(h5.shape[0]):
+        assert torch.equal(h5[i], got[3][i]), i
+    return got, ref

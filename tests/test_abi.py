@@ -100,7 +100,7 @@ def _null_fuzz(emu_lib, device):
     import parity_checks as P
     cd = emu_lib.cdll
     queries = {"od_version", "od_num_models", "od_model_name", "od_last_error", "od_model_indices", "od_model_dims",
-               "od_raw_grad_dims", "od_uses_cooperative", "od_bundle_workspace_bytes", "od_destroy"}
+               "od_raw_grad_dims", "od_uses_cooperative", "od_bundle_workspace_bytes", "od_destroy", "od_ilqr_destroy"}
     for name in sorted(_lib.SIGNATURES):
         fn = getattr(cd, name)
         r = fn(*_zero_args(fn))
@@ -118,12 +118,25 @@ def _null_fuzz(emu_lib, device):
             at = fn.argtypes or []
             if not at or at[0] is not C.c_void_p or name in ("od_destroy", "od_set_stream", "od_create"):
                 continue
+            if name.startswith("od_ilqr_") and name not in ("od_ilqr_create", "od_ilqr_backward"):
+                continue                                    # (their first argument is a solver object, not a handle: below)
             args = _zero_args(fn, h)
             for i, t in enumerate(at):                      # a batch of 4 problems / knots, null buffers
                 if i > 0 and t is C.c_long:
                     args[i] = 4
             r = fn(*args)
             assert isinstance(r, int) and r <= 0 or name in queries, (model, name, r)
+        # a live iLQR solver object without objective / initial trajectory, null data pointers
+        al = (C.c_double * 2)(1.0, 0.5)
+        s = C.c_void_p()
+        assert cd.od_ilqr_create(h, 4, 3, 2, al, None, C.byref(s)) == 0, cd.od_last_error()
+        for name in ("od_ilqr_init", "od_ilqr_iterate", "od_ilqr_al_update", "od_ilqr_solve", "od_ilqr_get", "od_ilqr_get_history",
+                     "od_ilqr_set_objective"):
+            fn = getattr(cd, name)
+            r = fn(*_zero_args(fn, s))
+            assert isinstance(r, int) and (r < 0 or (r == 0 and name == "od_ilqr_get_history")), (model, name, r)   # (no rows asked for: none)
+        assert cd.od_ilqr_get_info(s, None) < 0
+        assert cd.od_ilqr_destroy(s) == 0
 
 
 def test_null_arguments_are_error_codes_not_crashes(emu_lib):

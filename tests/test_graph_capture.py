@@ -73,3 +73,41 @@ def test_rocket_and_riccati_in_a_graph(gpu_lib):
         J = obj.value(X, Ut.double())                                                               # od_quad_cost
         return X, A, Bm, K, k, dV, J
     _capture_replay(run, lambda: Ut.add_(0.02), lambda o: o)
+
+
+@pytest.mark.parametrize("problem, dtype", [("rocket", torch.float32), ("rocket", torch.float64), ("cartpole", torch.float64)])
+def test_ilqr_iteration_in_a_graph(gpu_lib, problem, dtype):
+    """od_ilqr_iterate only enqueues kernels (no host synchronisation, no allocation, every decision on the device): ONE iteration
+    recorded in a HIP graph and replayed n times gives bit for bit the cost history, trajectories and gains of n direct iterations"""
+    import ilqr_checks as C
+    import optimization_dynamics_amd as od
+    B, T, n_it = 96, 20, 6
+    if problem == "rocket":
+        dyn, obj, x1, U0 = C.rocket_problem(gpu_lib, "cuda:0", B, T, dtype=dtype, seed=2)
+    else:
+        dyn, obj, x1, U0 = C.cartpole_problem(gpu_lib, "cuda:0", B, T, seed=2)
+    x1t, Ut = torch.tensor(x1, device="cuda:0"), torch.tensor(U0, device="cuda:0")
+    sol = od.ILQR(dyn, obj, T)
+    direct = sol.device_solver(B, max_iter=n_it, obj_tol=0.0)
+    direct.init(x1t, Ut)
+    direct.iterate(n_it)
+    want = direct.get(gains=True) + (direct.history(),)
+    assert want[-1].shape[0] == n_it
+    rec = sol.device_solver(B, max_iter=n_it, obj_tol=0.0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        rec.init(x1t, Ut)
+        rec.iterate(1)                           # warm-up on the capture stream
+        rec.init(x1t, Ut)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            rec.iterate(1)
+        # (capture does not execute: the solver still stands at its initial trajectory)
+        for _ in range(n_it):
+            g.replay()
+        torch.cuda.synchronize()
+        got = rec.get(gains=True) + (rec.history(),)
+        torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)

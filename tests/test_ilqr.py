@@ -63,6 +63,23 @@ def test_rocket_projection_ilqr_gpu_f32(oracle, gpu_lib):
     C.check_rocket_ilqr(oracle, gpu_lib, "cuda:0", B=64, T=40, dtype=torch.float32)
 
 
+def test_device_iteration_cpu(emu_lib):
+    """od_ilqr_solve against the loop composed on the host, cartpole with joint friction (terminal equality constraints:
+    two augmented-Lagrangian rounds) and the rocket with the thrust-cone projection in both precisions"""
+    C.check_device_iteration(emu_lib, "cpu", "cartpole")
+    C.check_device_iteration(emu_lib, "cpu", "rocket", B=3, T=10, max_iter=5, max_al_iter=1)
+    import torch
+    C.check_device_iteration(emu_lib, "cpu", "rocket", B=3, T=10, max_iter=5, max_al_iter=1, dtype=torch.float32)
+
+
+@pytest.mark.gpu
+def test_device_iteration_gpu(gpu_lib):
+    import torch
+    C.check_device_iteration(gpu_lib, "cuda:0", "cartpole", B=64, T=40)
+    C.check_device_iteration(gpu_lib, "cuda:0", "rocket", B=200, T=30, max_iter=6, max_al_iter=1)
+    C.check_device_iteration(gpu_lib, "cuda:0", "rocket", B=200, T=30, max_iter=6, max_al_iter=1, dtype=torch.float32)
+
+
 def test_reused_forward_states_cpu(emu_lib):
     C.check_reused_forward_states(emu_lib, "cpu", B=4, T=15)
 
@@ -79,3 +96,15 @@ def test_quad_cost_cpu(emu_lib):
 @pytest.mark.gpu
 def test_quad_cost_gpu(gpu_lib):
     C.check_quad_cost(gpu_lib, "cuda:0")
+
+
+def test_config5_inputs_cpu(oracle, emu_lib):
+    """the inputs of examples/rocket.jl (BASELINE config 5) through the whole chain on the host build, a handful of problems"""
+    C.check_config5(oracle, emu_lib, "cpu", B=3, iters=3)
+
+
+@pytest.mark.gpu
+def test_config5_rocket_projection_ilqr_as_stated(oracle, gpu_lib):
+    """BASELINE config 5 at its size: T = 61, u_max = 12.5, the example's x1 / objective / initial controls, 1024 problems x 11 step
+    sizes, double and single precision"""
+    C.check_config5(oracle, gpu_lib, "cuda:0", B=1024, iters=12)

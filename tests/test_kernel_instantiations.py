@@ -41,6 +41,14 @@ def test_rollout_8192_eight_lanes_per_problem(oracle, gpu_lib):
 
 
 @pytest.mark.gpu
+def test_config4_8192_rollouts_full_horizon(oracle, gpu_lib):
+    """BASELINE config 4 as stated, on one GPU: hopper, 8192 rollouts x T = 100 (k_rollout_state_coop3<Coop3_hopper>), against the
+    oracle's rollout on 256 trajectories over the full horizon, chained steps at the start, middle and end, and the same
+    trajectories in two batches of 4096 through the 16-lane kernel"""
+    P.check_rollout_instantiation(oracle, gpu_lib, "cuda:0", 8192, 100, 4096, n_oracle=256, t_chain=(0, 49, 99), same_form=False)
+
+
+@pytest.mark.gpu
 def test_rollout_12000_eight_lanes_two_wavefronts_per_simd(oracle, gpu_lib):
     """B = 12 000: k_rollout_state_coop3<Coop3_hopper, 2> (the 256-register build, 8193..16 384 rollouts); reference mapping: batches
     of 6000 through k_rollout_state_coop3<Coop3_hopper, 1> -- one kernel form, two builds: identical results"""
