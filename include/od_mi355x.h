@@ -82,6 +82,12 @@ int od_set_timestep(od_handle h, double dt);
 int od_set_friction(od_handle h, const double* mu, int n);
 /* RocketInfo.u_max (src/models/rocket/dynamics.jl:8) */
 int od_set_u_max(od_handle h, double u_max);
+/* The thrust-cone projection (soc_projection, src/models/rocket/dynamics.jl:168-186, eps_min = 0) can stall on the boundary of the
+ * cone away from the solution -- accepted step lengths ~1e-13 for the rest of its max_iter iterations, result reported as not
+ * converged (status bits 16 / 32 clear), in the CPU oracle alike; ~0.02 % of random controls.  on = 1 (default): such a solve is
+ * abandoned once its step length has been below 1e-9 for 4 consecutive iterations -- same status, the iterate within 1e-9 of
+ * the one the full loop returns -- so that a lockstep wavefront does not wait ~90 iterations for it.  on = 0: every iteration. */
+int od_set_projection_stall_exit(od_handle h, int on);
 int od_set_layout(od_handle h, int layout);
 /* A handle runs on one stream at a time (its gradient hand-over and staging workspaces are reused by consecutive
  * calls): changing the stream first waits for the work queued on the previous one.  Use one handle per stream for

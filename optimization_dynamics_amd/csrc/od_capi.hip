@@ -1122,6 +1122,7 @@ struct od_handle_s {
   int dtype, layout;
   od_options opts;
   double h, fric[4], u_max;
+  int proj_stall_exit;   // od_set_projection_stall_exit
   hipStream_t stream;
   int ppw;         // problems per wavefront; 0 = automatic (od_auto_ppw)
   int wpb;         // wavefronts per workgroup of the state pass: 0 automatic, 1 or 4
@@ -1298,7 +1299,7 @@ template <class T> static int rocket_impl(od_handle h, long B, int project, cons
   a.du = mkview<T>(du, 36, B, L);
   a.uproj = mkview<T>(uproj, 3, B, L);
   a.status = mkview<int>(status, 1, B, L);
-  a.skip = nullptr; a.live = nullptr; a.live_mod = 1;
+  a.skip = nullptr; a.live = nullptr; a.live_mod = 1; a.proj_stall_exit = h->proj_stall_exit;
   hipError_t e;
   if constexpr (sizeof(T) == 8) e = launch_rocket64(a, ppw_of(h, B), h->stream);
   else e = launch_rocket32(a, ppw_of(h, B), h->stream);
@@ -1320,7 +1321,7 @@ template <class T> static RocketArgs<T> rocket_args(od_handle h, long B, int pro
   a.project = project;
   a.want_grad = want_grad;
   a.x.p = nullptr; a.u.p = nullptr; a.y.p = nullptr; a.dx.p = nullptr; a.du.p = nullptr; a.uproj.p = nullptr; a.status.p = nullptr;
-  a.skip = nullptr; a.live = nullptr; a.live_mod = 1;
+  a.skip = nullptr; a.live = nullptr; a.live_mod = 1; a.proj_stall_exit = h->proj_stall_exit;
   return a;
 }
 
@@ -1451,6 +1452,7 @@ int od_create(int model, int dtype, const od_options* opts, double dt, od_handle
   h->h = dt;
   for (int i = 0; i < 4; ++i) h->fric[i] = vt->fric_default[i];
   h->u_max = 12.5;   // examples/rocket.jl:16
+  h->proj_stall_exit = 1;
   h->stream = nullptr;
   h->ppw = 0;
   h->coop = 0;
@@ -1500,6 +1502,11 @@ int od_set_friction(od_handle h, const double* mu, int n) {
 int od_set_u_max(od_handle h, double u_max) {
   if (!h) return fail(OD_ERR_INVALID, "od_set_u_max: null handle");
   h->u_max = u_max;
+  return OD_OK;
+}
+int od_set_projection_stall_exit(od_handle h, int on) {
+  if (!h) return fail(OD_ERR_INVALID, "od_set_projection_stall_exit: null handle");
+  h->proj_stall_exit = on ? 1 : 0;
   return OD_OK;
 }
 int od_set_layout(od_handle h, int layout) {

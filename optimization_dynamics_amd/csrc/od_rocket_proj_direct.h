@@ -1,0 +1,144 @@
+// The thrust-cone projection's KKT system in closed form (round 4).
+//
+// The reference factors the dense 10 x 10 Jacobian of the projection residual (src/models/rocket/codegen.jl:45-64) with partial
+// pivoting in every interior-point iteration of soc_projection (src/models/rocket/dynamics.jl:168-186).  The generated
+// elimination (gen/rocket_projection.h) takes the five structural -1 pivots statically and leaves a 5 x 5 tail with runtime
+// partial pivoting -- selects for every row exchange, 78 % of a closed-loop rocket rollout.  The system
+// has far more structure than that.  With  z = [u (3), p, s, w, y, v (3)],  a = u + v  and the right-hand side b:
+//
+//   rows 0-4 (pivots -1):   Dv01 = Du01 - b01,   Dv2 = Du2 - (Dy + Dp) - b2,   Ds = -Du2 - b3,   Dw = -Dy - b4
+//   rows 8, 9 (cone tail):  a2 Du_i + a_i Du2 - u_i (Dy + Dp) = c_{8+i},  i = 0, 1      pivot a2 = u2 + v2 > 0 (u, v in the cone)
+//   row 7 then:             E Du2 + G (Dy + Dp) = c7',   E = (a2^2 - a0^2 - a1^2) / a2 > 0,   G = (a0 u0 + a1 u1) / a2 - u2 <= 0
+//   rows 5, 6 (orthants):   -w Du2 - s Dy = c5,    p Du2 + u2 Dp = b6
+//
+// The last three lines are a 3 x 3 system in (Du2, Dy, Dp) whose determinant  G (w u2 + s p) - s u2 E  is a sum of terms of
+// one sign (E > 0 >= G; s, w, u2, p >= 0): it cannot cancel, vanishes only if the iterate is degenerate in both orthant pairs at
+// once, and Cramer's rule needs no pivot choice at all -- in particular none of the divisions by s or u2 that break a static
+// elimination when a full step (eps_min = 0, tau = 1) lands exactly on the boundary (codegen/models.py::rocket_projection).
+// Same linear system, solved exactly in another order: iterates agree with the pivoted elimination to rounding, i.e. up to the
+// line-search ties of this solve.
+#pragma once
+#include "gen/rocket_projection.h"
+
+namespace od {
+
+// sqrt(x) for the norm in the cone step: x * rsqrt(x) (the library's correctly rounded sqrt expands to ~28 instructions in single
+// precision, ~20 in double; four of them per interior-point iteration); 0 for x = 0
+template <class T> OD_HD T od_sqrt_fast(T x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OD_EXACT_RCP)
+  return x > T(0) ? x * od_rsqrt(x) : T(0);
+#else
+  return od_sqrt(x);
+#endif
+}
+
+struct Model_rocket_projection_direct : Model_rocket_projection {
+  static constexpr bool DIRECT_FACTOR = true;
+  // stall exit (od_solver.h::model_stall): the accepted step length below STALL_ALPHA in STALL_ITERS consecutive iterations
+  // (single precision: the guards of the cone step sit at 1e-7, a stalled solve creeps with step lengths of ~2e-6)
+  static constexpr double STALL_ALPHA = 1e-9, STALL_ALPHA_F32 = 1e-5;
+  static constexpr int STALL_ITERS = 4;
+  // step lengths of this model: hand-written (od_solver.h::model_direct_step) -- one 3-d cone, two orthant pairs
+  static constexpr bool DIRECT_STEP = true;
+
+  // The part of the CVXOPT sec. 8.2 cone step (od_solver.h::soc_step_one<3>) that depends on the cone variable lam alone: the
+  // predictor and the corrector step length of an iteration share it.
+  template <class T> struct ConePre { T l0, l1, l2, isq, ill, q; };
+  template <class T> OD_HD static ConePre<T> cone_pre(T l0, T l1, T l2) {
+    const T eps = sizeof(T) == 4 ? T(OD_SOC_EPS_F32) : T(1e-14);
+    T ll = l0 * l0;
+    ll -= l1 * l1;
+    ll -= l2 * l2;
+    ll = od_max(ll, sizeof(T) == 4 ? T(OD_SOC_FLOOR_F32) : T(1e-25)) + eps;
+    ConePre<T> p;
+    p.l0 = l0; p.l1 = l1; p.l2 = l2;
+    p.isq = od_rsqrt(ll);
+    p.ill = p.isq * p.isq;
+    p.q = od_rcp(l0 * p.isq + T(1));
+    return p;
+  }
+  // step to the boundary for lam - alpha * (D0, D1, D2)  (soc_step_one with dlt = -D)
+  template <class T> OD_HD static T cone_step(const ConePre<T>& p, T D0, T D1, T D2, T tau) {
+    const T eps = sizeof(T) == 4 ? T(OD_SOC_EPS_F32) : T(1e-14);
+    const T d0 = -D0, d1 = -D1, d2 = -D2;
+    T ld = p.l0 * d0;
+    ld -= p.l1 * d1;
+    ld -= p.l2 * d2;
+    ld += eps;
+    const T rs = ld * p.ill;
+    const T c = (ld * p.isq + d0) * p.q;
+    const T r1 = d1 * p.isq - c * p.l1 * p.ill, r2 = d2 * p.isq - c * p.l2 * p.ill;
+    const T nv = od_sqrt_fast(r1 * r1 + r2 * r2);
+    T a = T(1);
+    if (nv - rs > T(0)) a = od_min(a, tau * od_rcp(nv - rs));
+    return a;
+  }
+  template <class T> struct StepPre { ConePre<T> u, v; };
+  template <class T> OD_HD static StepPre<T> step_pre(const T* z) {
+    StepPre<T> p;
+    p.u = cone_pre<T>(z[2], z[0], z[1]);       // SOC1 = {2, 0, 1}
+    p.v = cone_pre<T>(z[9], z[7], z[8]);       // SOC2 = {9, 7, 8}
+    return p;
+  }
+  // largest alpha in (0, 1] keeping z - alpha D inside the cones (od_solver.h::step_length for this model)
+  template <class T> OD_HD static T direct_step_length(const StepPre<T>& p, const T* z, const T* D, T tau_ort, T tau_soc) {
+    // orthant pairs (s, w) and (u3, p): ORT1 = {4, 2}, ORT2 = {5, 3}; min of the ratio tests kept as a fraction
+    T num = T(1), den = T(1);
+    constexpr int K[4] = {4, 5, 2, 3};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const T n1 = tau_ort * z[K[i]];
+      if (D[K[i]] > T(0) && n1 * den < num * D[K[i]]) { num = n1; den = D[K[i]]; }
+    }
+    T a = num * od_rcp(den);
+    a = od_min(a, cone_step<T>(p.u, D[2], D[0], D[1], tau_soc));
+    a = od_min(a, cone_step<T>(p.v, D[9], D[7], D[8], tau_soc));
+    return a;
+  }
+  // u0 u1 u2 | s w | a0 a1 1/a2 | inverse of the 3 x 3 block, row-major (9)
+  template <class T> struct Fact { T v[17]; };
+
+  // z: the iterate with its orthant variables clamped (eval_factor); the Jacobian does not depend on theta
+  template <bool PIV = true, class T, class F> OD_HD static bool direct_factor(const T* z, F& f) {
+    const T u0 = z[0], u1 = z[1], u2 = z[2], p = z[3], s = z[4], w = z[5], v0 = z[7], v1 = z[8], v2 = z[9];
+    const T a0 = u0 + v0, a1 = u1 + v1, a2 = u2 + v2;
+    const bool oka = a2 != T(0);
+    const T ia2 = oka ? od_rcp(a2) : T(0);
+    const T E = a2 - (a0 * a0 + a1 * a1) * ia2;
+    const T G = (a0 * u0 + a1 * u1) * ia2 - u2;
+    const T pg = p * G - u2 * E, wg = w * G - s * E;            // (each a sum of two terms of one sign)
+    const T det = G * (w * u2 + s * p) - s * u2 * E;
+    const bool okd = det != T(0) && det == det;
+    const T id = okd ? od_rcp(det) : T(0);
+    f.v[0] = u0; f.v[1] = u1; f.v[2] = u2; f.v[3] = s; f.v[4] = w; f.v[5] = a0; f.v[6] = a1; f.v[7] = ia2;
+    // adj / det of  [-w -s 0; p 0 u2; E G G]
+    f.v[8] = -u2 * G * id;  f.v[9] = s * G * id;   f.v[10] = -s * u2 * id;
+    f.v[11] = -pg * id;     f.v[12] = -w * G * id; f.v[13] = w * u2 * id;
+    f.v[14] = p * G * id;   f.v[15] = wg * id;     f.v[16] = s * p * id;
+    return oka && okd;
+  }
+
+  // x = J^{-1} b (x may alias b)
+  template <bool PIV = true, class T, class F> OD_HD static void solve(const F& f, const T* b, T* x) {
+    const T u0 = f.v[0], u1 = f.v[1], u2 = f.v[2], s = f.v[3], w = f.v[4], a0 = f.v[5], a1 = f.v[6], ia2 = f.v[7];
+    const T b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b6 = b[6];
+    const T c5 = b[5] + w * b3 + s * b4;
+    const T c7 = b[7] + u0 * b0 + u1 * b1 + u2 * b2;
+    const T c8 = b[8] + u2 * b0 + u0 * b2;
+    const T c9 = b[9] + u2 * b1 + u1 * b2;
+    const T c7p = c7 - (a0 * c8 + a1 * c9) * ia2;
+    const T du2 = f.v[8] * c5 + f.v[9] * b6 + f.v[10] * c7p;
+    const T dy = f.v[11] * c5 + f.v[12] * b6 + f.v[13] * c7p;
+    const T dp = f.v[14] * c5 + f.v[15] * b6 + f.v[16] * c7p;
+    const T q = dy + dp;
+    const T du0 = (c8 - a0 * du2 + u0 * q) * ia2;
+    const T du1 = (c9 - a1 * du2 + u1 * q) * ia2;
+    x[0] = du0; x[1] = du1; x[2] = du2; x[3] = dp;
+    x[4] = -du2 - b3;
+    x[5] = -dy - b4;
+    x[6] = dy;
+    x[7] = du0 - b0; x[8] = du1 - b1; x[9] = du2 - q - b2;
+  }
+};
+
+}  // namespace od

@@ -265,6 +265,10 @@ template <class M, int C, class T> OD_HD void correction_cone(T* r, const T* Da)
 // rz evaluated with the orthant variables clamped from below at reg (regularisation of
 // rz!(ip, rz, z, theta; reg)), then factored.
 // PIV = false: the tail is factored down its diagonal (models with M::STATIC_TAIL, interior-point iterations only)
+// models with a hand-written closed-form elimination (od_rocket_proj_direct.h) declare `static constexpr bool DIRECT_FACTOR = true`
+template <class M, class = void> struct model_direct_factor : std::false_type {};
+template <class M> struct model_direct_factor<M, std::void_t<decltype(M::DIRECT_FACTOR)>> : std::bool_constant<M::DIRECT_FACTOR> {};
+
 template <class M, bool PIV = true, class T, class F>
 OD_HD bool eval_factor(const T* z, const T* th, const T* pre, const T* tr, T reg, F& f) {
   T zr[M::NZ];
@@ -277,9 +281,13 @@ OD_HD bool eval_factor(const T* z, const T* th, const T* pre, const T* tr, T reg
       zr[M::ORT2[i]] = od_max(zr[M::ORT2[i]], reg);
     }
   }
-  T a[M::NNZ];
-  M::eval_rz(zr, th, pre, tr, a);
-  return M::template factor<PIV>(a, f);
+  if constexpr (model_direct_factor<M>::value) {
+    return M::template direct_factor<PIV>(zr, f);
+  } else {
+    T a[M::NNZ];
+    M::eval_rz(zr, th, pre, tr, a);
+    return M::template factor<PIV>(a, f);
+  }
 }
 
 // backtracking on z - alpha D until either violation does not increase (at most max_ls trials, the last one is kept
@@ -287,7 +295,9 @@ OD_HD bool eval_factor(const T* z, const T* th, const T* pre, const T* tr, T reg
 // Models up to the hopper's size, when lanes carry copies (Opts::coop): a solve that jams spends most of its time here (acrobot at its joint
 // limit: ~15 trials in each of its 100 iterations), so after two sequential trials the 16/ppw copies each try a step
 // size, agree on the first accepted one (the same one the sequential loop would find) and re-evaluate it.
-template <class M> constexpr bool parallel_line_search() { return M::NZ <= 20; }
+template <class M, class = void> struct model_no_lane_copies : std::false_type {};
+template <class M> struct model_no_lane_copies<M, std::void_t<decltype(M::DIRECT_STEP)>> : std::true_type {};   // (the rocket kernels map one problem to one lane)
+template <class M> constexpr bool parallel_line_search() { return M::NZ <= 20 && !model_no_lane_copies<M>::value; }
 
 template <class M, class T>
 OD_HD bool ls_trial(const T* th, const T* pre, T* tr, const T* z, const T* D, T alpha, T r_vio, T k_vio, T* zc, T* r, T& r_c, T& k_c) {
@@ -343,9 +353,13 @@ OD_HD void line_search(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z,
 // One predictor-corrector iteration at z (r = r(z; 0), r_vio / k_vio its violations): factor, affine
 // direction, centering, corrector direction, step length, backtracking line search.  Shared by the
 // lockstep loop below and the decoupled rollout (od_units.h) so that both do identical arithmetic.
+// models with hand-written step lengths (od_rocket_proj_direct.h) declare `static constexpr bool DIRECT_STEP = true`
+template <class M, class = void> struct model_direct_step : std::false_type {};
+template <class M> struct model_direct_step<M, std::void_t<decltype(M::DIRECT_STEP)>> : std::bool_constant<M::DIRECT_STEP> {};
+
 template <class M, class T, class F>
 OD_HD void ip_iteration(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z, T* r, T& r_vio, T& k_vio, T& reg_prev,
-                        int& status, int it, F& f) {
+                        int& status, int it, F& f, T* alpha_out = nullptr) {
   constexpr bool CONES = (M::NORT + M::NSOC) > 0;
   const T reg = (k_vio < o.kappa_reg) ? k_vio * o.gamma_reg : T(0);
   reg_prev = reg;
@@ -353,8 +367,17 @@ OD_HD void ip_iteration(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z
   if (!eval_factor<M, PIV>(z, th, pre, tr, reg, f)) status &= ~OD_ST_FACTOR_OK;
   T D[M::NZ];
   M::template solve<PIV>(f, r, D);                     // affine (predictor) direction
+  auto steplen = [&](const T* D_, T tau_ort, T tau_soc, const auto& pre_) {
+    if constexpr (model_direct_step<M>::value) return M::template direct_step_length<T>(pre_, z, D_, tau_ort, tau_soc);
+    else return step_length<M>(z, D_, tau_ort, tau_soc, o.coop);
+  };
+  auto make_pre = [&]() {
+    if constexpr (model_direct_step<M>::value) return M::template step_pre<T>(z);
+    else return 0;
+  };
+  const auto spre = make_pre();                        // (what the two step lengths of an iteration share)
   if constexpr (CONES) {
-    const T aaff = step_length<M>(z, D, T(1), T(1), o.coop);
+    const T aaff = steplen(D, T(1), T(1), spre);
     T kap = centering_kappa<M>(z, D, aaff);
     kap = od_max(kap, o.kappa_eval * o.undercut_inv);
 #pragma unroll
@@ -368,11 +391,12 @@ OD_HD void ip_iteration(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z
   }
   const T vio = od_max(r_vio, k_vio);
   const T tau = T(1) - od_min(o.eps_min, vio * vio);
-  T alpha = step_length<M>(z, D, tau, od_min(tau, T(0.99)), o.coop);
+  T alpha = steplen(D, tau, od_min(tau, T(0.99)), spre);
 #ifdef OD_TRACE
   const T alpha0_ = alpha;
 #endif
   line_search<M>(o, th, pre, tr, z, D, alpha, r, r_vio, k_vio);
+  if (alpha_out) *alpha_out = alpha;
   OD_TRACE_IT("dev it %d alpha %.17g r_vio %.6e k_vio %.6e alpha0 %.6e\n", it + 1, (double)alpha, (double)r_vio, (double)k_vio, (double)alpha0_);
 }
 
@@ -380,12 +404,23 @@ OD_HD void ip_iteration(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z
 template <class S, class = void> struct sink_all_rows : std::false_type {};
 template <class S> struct sink_all_rows<S, std::void_t<decltype(S::ALL_ROWS)>> : std::bool_constant<S::ALL_ROWS> {};
 
+// Stall exit (models that declare STALL_ALPHA / STALL_ITERS: the thrust-cone projection, od_rocket_proj_direct.h).  With eps_min = 0
+// the projection's iterates can run into the boundary of the cone away from the solution (~0.02 % of random controls, 0.2 % of
+// the controls of config 5's first iterations, in the oracle alike): the step to the boundary shrinks 100x per iteration, the
+// accepted step length ends at ~1e-13 -- the guards of the cone step keep it from being exactly zero -- and the solve creeps through
+// its remaining ~85 iterations moving the iterate by less than 1e-11 in total, to be reported as not converged.  A lockstep
+// wavefront waits for it.  When the accepted step length has been below STALL_ALPHA for STALL_ITERS consecutive iterations the
+// solve is abandoned as if max_iter had been reached (same status bits, iteration count = max_iter, the iterate within
+// (max_iter - it) * STALL_ALPHA * |D| of the one the full loop would return).  od_set_projection_stall_exit(h, 0) runs every iteration.
+template <class M, class = void> struct model_stall : std::false_type {};
+template <class M> struct model_stall<M, std::void_t<decltype(M::STALL_ITERS)>> : std::true_type {};
+
 // Sink concept:  void grad(int i /*row in ZQ*/, int c /*grad column*/, T v)
 //
 // z: in = initial guess, out = iterate at (r_tol, kappa_eval) convergence (or the last iterate).
 // Returns status bits; iters[0] = iterations to kappa_eval, iters[1] = iterations to kappa_grad.
 template <class M, class T, class Sink, class F>
-OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, bool want_grad, Sink& sink, int* iters, F& f) {
+OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, bool want_grad, Sink& sink, int* iters, F& f, bool stall_exit = false) {
   // state snapshot at (r_tol, kappa_eval): the whole z for raw solves, only the next configuration otherwise
   constexpr int NSNAP = Sink::FULL_STATE ? M::NZ : M::NZQ;
   T r[M::NZ], zs[NSNAP], pre[M::NPRE], tr[M::NTR];
@@ -397,6 +432,7 @@ OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, boo
   T reg_prev = T(0);
   iters[0] = iters[1] = 0;
   int it = 0;
+  int nstall = 0;
   for (;; ++it) {
     const bool req = r_vio < o.r_tol;
     const bool last = it >= o.max_iter;
@@ -440,7 +476,14 @@ OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, boo
     }
     if (eval_done && grad_done) break;
 
-    ip_iteration<M>(o, th, pre, tr, z, r, r_vio, k_vio, reg_prev, status, it, f);
+    if constexpr (model_stall<M>::value) {
+      T alpha;
+      ip_iteration<M>(o, th, pre, tr, z, r, r_vio, k_vio, reg_prev, status, it, f, &alpha);
+      nstall = (alpha < T(sizeof(T) == 4 ? M::STALL_ALPHA_F32 : M::STALL_ALPHA)) ? nstall + 1 : 0;
+      if (stall_exit && nstall >= M::STALL_ITERS && it + 1 < o.max_iter) it = o.max_iter - 1;
+    } else {
+      ip_iteration<M>(o, th, pre, tr, z, r, r_vio, k_vio, reg_prev, status, it, f);
+    }
   }
   if (want_state) {
 #pragma unroll
@@ -474,9 +517,9 @@ template <class M, class T, class Sink> OD_HD bool gradient_at(const T* th, cons
 
 // convenience: factor storage in registers
 template <class M, class T, class Sink>
-OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, bool want_grad, Sink& sink, int* iters) {
+OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, bool want_grad, Sink& sink, int* iters, bool stall_exit = false) {
   typename M::template Fact<T> f;
-  return ip_step_grad<M, T, Sink>(o, th, z, want_state, want_grad, sink, iters, f);
+  return ip_step_grad<M, T, Sink>(o, th, z, want_state, want_grad, sink, iters, f, stall_exit);
 }
 
 // theta = [q2 - h*v1 ; q2 ; u ; friction ; h] and z0 = initialize_z!(q2) for the mechanical models

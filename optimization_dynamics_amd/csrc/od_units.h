@@ -438,6 +438,7 @@ template <class T> struct RocketArgs {
   const int* skip;    // non-zero = the launch does nothing
   const int* live;    // per trajectory: knot b belongs to trajectory b % live_mod and is computed only if live[b % live_mod] != 0
   long live_mod;
+  int proj_stall_exit; // 1: a projection solve that has stalled at the boundary of the cone is abandoned (od_solver.h::model_stall)
 };
 
 // d(projected u)/du: 3 x 3 col-major kept in registers (column index is dynamic -> selects)
@@ -469,6 +470,32 @@ template <class T> struct RocketDynSink {
 };
 
 // one rocket knot: (x, u) in registers -> y in registers; per-knot outputs (dx, du, uproj, status) at index b
+// GRADS = false (the rollout kernels): state only -- no gradient code in the kernel at all (it would never run there, but its
+// arrays would still shape the register allocation of the time recursion)
+template <class MD, class MP, class T> OD_HD void rocket_knot_state(const RocketArgs<T>& a, long b, const T* x, T* u, T* y) {
+  int st = 0;
+  NoGradSink<T> ns;
+  if (a.project) {
+    T zp[MP::NZ], thp[MP::NTH];
+#pragma unroll
+    for (int i = 0; i < MP::NZ; ++i) zp[i] = T(MP::ZI_VAL[i]);
+    thp[0] = u[0]; thp[1] = u[1]; thp[2] = u[2]; thp[3] = a.u_max;
+    int itp[2];
+    const int sp_ = ip_step_grad<MP>(a.opts_proj, thp, zp, true, false, ns, itp, a.proj_stall_exit != 0);
+    st |= (sp_ & 1) << 4;
+    u[0] = zp[0]; u[1] = zp[1]; u[2] = zp[2];
+    if (a.uproj.ok()) { a.uproj.at(0, b) = u[0]; a.uproj.at(1, b) = u[1]; a.uproj.at(2, b) = u[2]; }
+  }
+  T th[MD::NTH];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { th[i] = x[i]; y[i] = x[i]; }
+  th[12] = u[0]; th[13] = u[1]; th[14] = u[2]; th[15] = a.h;
+  int it[2];
+  const int sd = ip_step_grad<MD>(a.opts_dyn, th, y, true, false, ns, it);
+  st |= (sd & (OD_ST_EVAL_OK | OD_ST_FACTOR_OK));
+  if (a.status.ok()) a.status.at(0, b) = st;
+}
+
 template <class MD, class MP, class T>
 OD_HD void rocket_knot(const RocketArgs<T>& a, long b, const T* x, T* u, T* y) {
   int st = 0;
@@ -483,7 +510,7 @@ OD_HD void rocket_knot(const RocketArgs<T>& a, long b, const T* x, T* u, T* y) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) dproj[i] = T(0);
     int itp[2];
-    const int sp_ = ip_step_grad<MP>(a.opts_proj, thp, zp, true, a.want_grad != 0, ps, itp);
+    const int sp_ = ip_step_grad<MP>(a.opts_proj, thp, zp, true, a.want_grad != 0, ps, itp, a.proj_stall_exit != 0);
     st |= (sp_ & 3) << 4;
     u[0] = zp[0]; u[1] = zp[1]; u[2] = zp[2];
     if (a.uproj.ok()) { a.uproj.at(0, b) = u[0]; a.uproj.at(1, b) = u[1]; a.uproj.at(2, b) = u[2]; }
@@ -532,7 +559,7 @@ template <class MP, class T> OD_HD void unit_soc_project(const RocketArgs<T>& a,
   for (int i = 0; i < 9; ++i) dproj[i] = T(0);
   ProjSink<T> ps{dproj};
   int itp[2];
-  const int sp_ = ip_step_grad<MP>(a.opts_proj, thp, zp, true, a.want_grad != 0, ps, itp);
+  const int sp_ = ip_step_grad<MP>(a.opts_proj, thp, zp, true, a.want_grad != 0, ps, itp, a.proj_stall_exit != 0);
   if (a.uproj.ok()) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) a.uproj.at(i, b) = zp[i];
@@ -600,7 +627,7 @@ template <class MD, class MP, class T> OD_HD void unit_rocket_rollout(const Rock
 #pragma unroll
       for (int j = 0; j < 3; ++j) ra.U.at(j, kc) = u[j];
     }
-    rocket_knot<MD, MP, T>(a, kc, x, u, y);
+    rocket_knot_state<MD, MP, T>(a, kc, x, u, y);
     if (a.y.ok()) {
 #pragma unroll
       for (int i = 0; i < 12; ++i) a.y.at(i, kc) = y[i];

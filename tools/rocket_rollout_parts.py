@@ -28,3 +28,8 @@ for proj in (True, False):
     print("project=%s closed loop (%d candidates): %.3f ms" % (proj, na * B, timeit(lambda: rk._rocket_rollout(info, x1t, Ut, proj, policy=(alphas, X, K, k)))))
     print("project=%s open loop   (%d rollouts):   %.3f ms" % (proj, na * B, timeit(lambda: rk._rocket_rollout(info, x1big, Ubig, proj))))
     print("project=%s open loop   (%d rollouts):   %.3f ms" % (proj, B, timeit(lambda: rk._rocket_rollout(info, x1t, Ut, proj))))
+# lane mapping: fewer candidates per wavefront (more wavefronts in flight per SIMD)
+for ppw in (64, 32, 16):
+    lib.check(lib.cdll.od_set_launch_config(info._h, ppw, 0))
+    print("ppw=%d project=True closed loop (%d candidates): %.3f ms" % (ppw, na * B, timeit(lambda: rk._rocket_rollout(info, x1t, Ut, True, policy=(alphas, X, K, k)))))
+lib.check(lib.cdll.od_set_launch_config(info._h, 0, 0))
