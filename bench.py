@@ -192,6 +192,7 @@ def main():
     ap.add_argument("--gather", action="store_true", help="all-gather the compact linearisation (x+, dq3) after every step (RCCL)")
     ap.add_argument("--dense", action="store_true", help="write the dense fx / fu matrices (od_rollout) instead of the compact dq3 (od_rollout_compact)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux-configs", action="store_true", help="skip the aux_config_2 / 3 / 5 blocks (bench_configs.py)")
     ap.add_argument("--ppw", type=int, default=0, help="problems per wavefront (0 = library default)")
     ap.add_argument("--wpb", type=int, default=0, help="wavefronts per workgroup of the solve pass: 1 or 4 (0 = library default)")
     ap.add_argument("--coop", type=int, default=0, help="cooperative solve pass: 0 automatic, 1 never, 2 always")
@@ -436,6 +437,10 @@ def main():
             aux["algorithmic_tflops"] = Fk * aux["units_per_s"] / 1e12
             aux["algorithmic_frac"] = aux["algorithmic_tflops"] / FP64_PEAK_TFLOPS     # dense-LU flop count over time: useful work, not hardware utilisation
             line["aux_independent_knots"] = aux
+        if not args.no_cpu_baseline and world == 1 and not emu and not args.no_aux_configs:
+            # the other BASELINE.json configs with their own roofline and CPU baseline (bench_configs.py)
+            import bench_configs
+            line.update(bench_configs.all_configs(dev, cpu=True))
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(B, T, seed=0)

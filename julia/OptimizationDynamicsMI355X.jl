@@ -19,7 +19,8 @@ using LinearAlgebra
 export ImplicitDynamics, f, fx, fu, state_to_configuration, GradientBundle, fx_gb, fu_gb,
        RocketInfo, f_rocket, fx_rocket, fu_rocket, f_rocket_proj, fx_rocket_proj, fu_rocket_proj,
        soc_projection, soc_projection_gradient, ffxfu!,
-       od_step_grad!, od_rollout!, od_rollout_compact!, od_rocket!, od_soc_project!, od_step_full!, model_indices
+       od_step_grad!, od_rollout!, od_rollout_compact!, od_rocket!, od_soc_project!, od_step_full!, model_indices,
+       ILQRSolver, initialize!, iterate!, al_update!, solve!, get_trajectory!
 
 const LIB = get(ENV, "OD_MI355X_LIB", joinpath(@__DIR__, "..", "optimization_dynamics_amd", "libod_mi355x.so"))
 
@@ -296,6 +297,62 @@ function od_rocket!(r::RocketInfo, B, project::Bool, X, U, Y, DX, DU)
     check(ccall((:od_set_layout, LIB), Cint, (Ptr{Cvoid}, Cint), r.h, 1))
     check(ccall((:od_rocket, LIB), Cint, (Ptr{Cvoid}, Clong, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}),
                 r.h, B, project ? 1 : 0, pointer(X), pointer(U), pointer(Y), pointer(DX), pointer(DU), C_NULL, C_NULL))
+end
+
+# ---- the iLQR iteration on the device (od_ilqr_*): iLQR.solver / solve! for B problems in lockstep ------------------------------
+# Counterpart of the reference's use of IterativeLQR.jl (examples/acrobot.jl:97-113, examples/rocket.jl:118-139) for quadratic
+# objectives and terminal equality constraints.  Device arrays are batch-minor: x1 is B x n, U is B x T x m, X is B x (T+1) x n
+# (Julia column-major: element (b, t, i) at b + B (t + T i)), all Float64.
+struct ILQROptions                    # od_ilqr_options
+    reg::Cdouble; c1::Cdouble; obj_tol::Cdouble; con_tol::Cdouble; rho_init::Cdouble; rho_scale::Cdouble
+    max_iter::Cint; max_al_iter::Cint; project::Cint; history::Cint
+end
+struct ILQRInfo                       # od_ilqr_info
+    iterations::Cint; al_iterations::Cint; done::Cint; al_done::Cint; bad_linearisations::Cint
+    reg::Cdouble; rho::Cdouble; max_dJ::Cdouble; max_violation::Cdouble
+end
+mutable struct ILQRSolver
+    s::Ptr{Cvoid}
+    owner::Any                        # the ImplicitDynamics / RocketInfo whose handle the solver borrows (kept alive)
+    B::Int; T::Int
+end
+
+"""
+    ILQRSolver(dyn, B, T; alphas, Q, R, QT, xref, goal_idx, goal, obj_tol, con_tol, max_iter, max_al_iter, ρ_init, ρ_scale, project)
+
+`dyn`: an ImplicitDynamics or a RocketInfo.  Objective Σ ½(x-xref)'Q(x-xref) + ½u'Ru + ½(x_T-xref)'QT(x_T-xref); terminal
+constraints x_T[goal_idx] = goal by augmented Lagrangian (cf. iLQR.Options, examples/acrobot.jl:98-107).
+"""
+function ILQRSolver(dyn, B::Integer, T::Integer; alphas=[2.0^-i for i in 0:10], Q, R, QT, xref,
+        goal_idx=Int[], goal=Float64[], reg=1.0e-6, c1=1.0e-4, obj_tol=1.0e-6, con_tol=1.0e-3, max_iter=50, max_al_iter=1,
+        ρ_init=1.0, ρ_scale=10.0, project=true, history=0)
+    o = Ref(ILQROptions(reg, c1, obj_tol, con_tol, ρ_init, ρ_scale, max_iter, max_al_iter, project ? 1 : 0, history))
+    hd = Ref{Ptr{Cvoid}}(C_NULL)
+    a = Float64.(collect(alphas))
+    check(ccall((:od_ilqr_create, LIB), Cint, (Ptr{Cvoid}, Clong, Cint, Cint, Ptr{Cdouble}, Ref{ILQROptions}, Ref{Ptr{Cvoid}}),
+                dyn.h, B, T, length(a), a, o, hd))
+    gi = Cint.(collect(goal_idx) .- 1)                                 # 0-based rows of x_T
+    check(ccall((:od_ilqr_set_objective, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cint}, Ptr{Cdouble}),
+                hd[], Matrix{Float64}(Q), Matrix{Float64}(R), Matrix{Float64}(QT), Float64.(collect(xref)), length(gi), gi, Float64.(collect(goal))))
+    s = ILQRSolver(hd[], dyn, B, T)
+    finalizer(x -> ccall((:od_ilqr_destroy, LIB), Cint, (Ptr{Cvoid},), x.s), s)
+    return s
+end
+
+"initialize_controls! + rollout + first linearisation (examples/acrobot.jl:108-113); x1, U0 device arrays"
+initialize!(s::ILQRSolver, x1, U0) = check(ccall((:od_ilqr_init, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), s.s, pointer(x1), pointer(U0)))
+"n iterations, asynchronous (no host synchronisation; capturable in a HIP graph)"
+iterate!(s::ILQRSolver, n::Integer=1) = check(ccall((:od_ilqr_iterate, LIB), Cint, (Ptr{Cvoid}, Cint), s.s, n))
+al_update!(s::ILQRSolver) = check(ccall((:od_ilqr_al_update, LIB), Cint, (Ptr{Cvoid},), s.s))
+"solve!(solver, x1, U0) -- examples/acrobot.jl:113"
+solve!(s::ILQRSolver, x1, U0) = check(ccall((:od_ilqr_solve, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), s.s, pointer(x1), pointer(U0)))
+"get_trajectory(solver) -- examples/acrobot.jl:121: X (B x (T+1) x n), U (B x T x m), J (B) device arrays, filled asynchronously"
+get_trajectory!(s::ILQRSolver, X, U, J) =
+    check(ccall((:od_ilqr_get, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), s.s, pointer(X), pointer(U), pointer(J), C_NULL, C_NULL))
+function info(s::ILQRSolver)
+    r = Ref(ILQRInfo(0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0))
+    check(ccall((:od_ilqr_get_info, LIB), Cint, (Ptr{Cvoid}, Ref{ILQRInfo}), s.s, r))
+    return r[]
 end
 
 end # module

@@ -1,0 +1,50 @@
+"""SURVEY.md 8(f).4, the part that can be built here: the reference's comparison of implicit gradients against FINITE-DIFFERENCE
+Jacobians inside iLQR (examples/comparisons/acrobot/acrobot.jl:30-36; MuJoCo there, the CPU oracle's own step here --
+oracle/fd_validator.py) on the acrobot swing-up of examples/acrobot.jl, and the same task through the device-resident solver."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+
+def _device_solution(lib, device, B):
+    import optimization_dynamics_amd as od
+    from optimization_dynamics_amd import ilqr as IL
+    h, T = 0.05, 100
+    im = od.ImplicitDynamics(od.acrobot_impact, h, r_tol=1e-8, kappa_eval_tol=1e-4, kappa_grad_tol=1e-3, device=device, lib=lib)
+    I2 = np.eye(2)
+    Q = 0.1 / h ** 2 * np.block([[I2, -I2], [-I2, I2]])
+    xT = np.array([math.pi, 0.0, math.pi, 0.0])
+    obj = IL.QuadraticObjective(Q, np.eye(1), Q, x_ref=np.zeros(4), goal_idx=[0, 1, 2, 3], goal=xT, device=device)
+    U0 = np.stack([1e-3 * np.random.default_rng(1 + b).normal(size=(1, T)) for b in range(B)], axis=-1)     # (trajectory 0: the validator's)
+    sol = IL.ILQR(im, obj, T)
+    X, U, J, hist = sol.solve(torch.zeros(4, B, dtype=torch.float64, device=device), torch.tensor(U0, device=device),
+                              max_iter=50, max_al_iter=20, con_tol=1e-3, obj_tol=1e-5)
+    viol = (X[:, -1] - torch.tensor(xT, device=device)[:, None]).abs().max(0).values
+    return obj.value(X, U).cpu().numpy(), viol.cpu().numpy(), sol._dev.info()
+
+
+def test_finite_difference_jacobians_against_implicit_gradients(oracle, emu_lib):
+    from oracle import fd_validator as V
+    imp = V.solve("implicit")
+    fd = V.solve("fd")
+    # both reach the goal of examples/acrobot.jl to its con_tol (:104), with comparable objectives: the implicit gradient at
+    # kappa_grad = 1e-3 is a usable search direction, as is the finite difference of the kappa_eval = 1e-4 step
+    assert imp["violation"] < 1e-3 and fd["violation"] < 1e-3, (imp["violation"], fd["violation"])
+    assert abs(imp["objective"] - fd["objective"]) < 0.1 * fd["objective"], (imp["objective"], fd["objective"])
+    print("acrobot swing-up, CPU oracle: implicit gradients J = %.3f in %d iterations; finite differences J = %.3f in %d iterations"
+          % (imp["objective"], imp["iterations"], fd["objective"], fd["iterations"]))
+    # the device-resident solver (host build of the same sources) on the same task and initial controls
+    J, viol, info = _device_solution(emu_lib, "cpu", 2)
+    assert viol.max() < 1e-3 and info.al_done == 1
+    assert abs(J[0] - imp["objective"]) < 0.1 * imp["objective"], (J[0], imp["objective"])
+
+
+@pytest.mark.gpu
+def test_acrobot_swing_up_on_the_device(gpu_lib):
+    """examples/acrobot.jl (T = 101, terminal equality constraint by augmented Lagrangian, options of :98-108) through od_ilqr_solve,
+    64 problems: every one reaches the goal to con_tol; objective in the range the CPU validator finds (77-80)"""
+    J, viol, info = _device_solution(gpu_lib, "cuda:0", 64)
+    assert viol.max() < 1e-3 and info.al_done == 1, (viol.max(), info.al_done)
+    assert (J > 60).all() and (J < 100).all(), (J.min(), J.max())
