@@ -88,6 +88,12 @@ int od_set_u_max(od_handle h, double u_max);
  * abandoned once its step length has been below 1e-9 for 4 consecutive iterations -- same status, the iterate within 1e-9 of
  * the one the full loop returns -- so that a lockstep wavefront does not wait ~90 iterations for it.  on = 0: every iteration. */
 int od_set_projection_stall_exit(od_handle h, int on);
+/* OD_F32 rocket handles (BASELINE config 5 asks for single precision): on = 1 (default) finishes every dynamics step with ONE
+ * Newton step of the same residual in double at the single-precision solution and takes the implicit gradient -rz^{-1} rtheta
+ * from that double factorisation; results are rounded to float on the way out.  States then agree with the double-precision
+ * solve to float resolution (within the 1e-6 / 1e-4 bars); on = 0: single precision throughout (5e-4 / 2e-2).  The thrust-cone
+ * projection stays in single precision either way (its result is kappa_tol = 1e-4 accurate by construction).  No effect on OD_F64. */
+int od_set_mixed_precision(od_handle h, int on);
 int od_set_layout(od_handle h, int layout);
 /* A handle runs on one stream at a time (its gradient hand-over and staging workspaces are reused by consecutive
  * calls): changing the stream first waits for the work queued on the previous one.  Use one handle per stream for

@@ -67,6 +67,7 @@ SIGNATURES = {
     "od_set_u_max": (C.c_int, [_VP, C.c_double]),
     "od_set_layout": (C.c_int, [_VP, C.c_int]),
     "od_set_projection_stall_exit": (C.c_int, [_VP, C.c_int]),
+    "od_set_mixed_precision": (C.c_int, [_VP, C.c_int]),
     "od_set_stream": (C.c_int, [_VP, _VP]),
     "od_set_launch_config": (C.c_int, [_VP, C.c_int, C.c_int]),
     "od_set_cooperative": (C.c_int, [_VP, C.c_int]),

@@ -1123,6 +1123,7 @@ struct od_handle_s {
   od_options opts;
   double h, fric[4], u_max;
   int proj_stall_exit;   // od_set_projection_stall_exit
+  int polish64;          // od_set_mixed_precision
   hipStream_t stream;
   int ppw;         // problems per wavefront; 0 = automatic (od_auto_ppw)
   int wpb;         // wavefronts per workgroup of the state pass: 0 automatic, 1 or 4
@@ -1299,7 +1300,7 @@ template <class T> static int rocket_impl(od_handle h, long B, int project, cons
   a.du = mkview<T>(du, 36, B, L);
   a.uproj = mkview<T>(uproj, 3, B, L);
   a.status = mkview<int>(status, 1, B, L);
-  a.skip = nullptr; a.live = nullptr; a.live_mod = 1; a.proj_stall_exit = h->proj_stall_exit;
+  a.skip = nullptr; a.live = nullptr; a.live_mod = 1; a.proj_stall_exit = h->proj_stall_exit; a.polish64 = h->polish64; a.h64 = h->h;
   hipError_t e;
   if constexpr (sizeof(T) == 8) e = launch_rocket64(a, ppw_of(h, B), h->stream);
   else e = launch_rocket32(a, ppw_of(h, B), h->stream);
@@ -1321,7 +1322,7 @@ template <class T> static RocketArgs<T> rocket_args(od_handle h, long B, int pro
   a.project = project;
   a.want_grad = want_grad;
   a.x.p = nullptr; a.u.p = nullptr; a.y.p = nullptr; a.dx.p = nullptr; a.du.p = nullptr; a.uproj.p = nullptr; a.status.p = nullptr;
-  a.skip = nullptr; a.live = nullptr; a.live_mod = 1; a.proj_stall_exit = h->proj_stall_exit;
+  a.skip = nullptr; a.live = nullptr; a.live_mod = 1; a.proj_stall_exit = h->proj_stall_exit; a.polish64 = h->polish64; a.h64 = h->h;
   return a;
 }
 
@@ -1453,6 +1454,7 @@ int od_create(int model, int dtype, const od_options* opts, double dt, od_handle
   for (int i = 0; i < 4; ++i) h->fric[i] = vt->fric_default[i];
   h->u_max = 12.5;   // examples/rocket.jl:16
   h->proj_stall_exit = 1;
+  h->polish64 = 1;
   h->stream = nullptr;
   h->ppw = 0;
   h->coop = 0;
@@ -1507,6 +1509,11 @@ int od_set_u_max(od_handle h, double u_max) {
 int od_set_projection_stall_exit(od_handle h, int on) {
   if (!h) return fail(OD_ERR_INVALID, "od_set_projection_stall_exit: null handle");
   h->proj_stall_exit = on ? 1 : 0;
+  return OD_OK;
+}
+int od_set_mixed_precision(od_handle h, int on) {
+  if (!h) return fail(OD_ERR_INVALID, "od_set_mixed_precision: null handle");
+  h->polish64 = on ? 1 : 0;
   return OD_OK;
 }
 int od_set_layout(od_handle h, int layout) {

@@ -439,6 +439,8 @@ template <class T> struct RocketArgs {
   const int* live;    // per trajectory: knot b belongs to trajectory b % live_mod and is computed only if live[b % live_mod] != 0
   long live_mod;
   int proj_stall_exit; // 1: a projection solve that has stalled at the boundary of the cone is abandoned (od_solver.h::model_stall)
+  int polish64;        // single-precision handles: 1 = one Newton step of the dynamics residual and the implicit gradient in double (rocket_polish64)
+  double h64;          // the time step in double (h is rounded to T)
 };
 
 // d(projected u)/du: 3 x 3 col-major kept in registers (column index is dynamic -> selects)
@@ -469,6 +471,73 @@ template <class T> struct RocketDynSink {
   }
 };
 
+// Mixed precision for the single-precision handles (BASELINE config 5; SURVEY.md section 7: "keep the final Newton refinement in
+// fp64").  The single-precision Newton iteration of the dynamics step stops at r_tol = 1e-4 -- 1e-8 is below the resolution of
+// float -- and its implicit gradient carries the conditioning of a float LU.  One more Newton step of the SAME residual in double
+// at the float solution (inputs x, u as the floats they are, the time step in double) squares the error away, and -rz^{-1} rtheta
+// with that double factorisation gives the gradient; both are rounded to float on the way out, so the results are the
+// double-precision answers to float resolution (6e-8) -- inside the north_star's 1e-6 / 1e-4 -- for one factorisation of a
+// 12 x 12 system with 44 factor entries.  The thrust-cone projection stays in single precision: its result is only
+// kappa_tol = 1e-4 accurate by construction.
+template <class S> struct CastSink64 {
+  S& s;
+  OD_HD void grad(int i, int c, double v) { s.grad(i, c, (float)v); }
+};
+template <class MD, class Sink> OD_HD bool rocket_polish64(const float* x, const float* u, double h, float* y, bool want_grad, Sink& sink) {
+  double th[MD::NTH], z[MD::NZ], r[MD::NZ], D[MD::NZ], pre[MD::NPRE > 0 ? MD::NPRE : 1], tr[MD::NTR > 0 ? MD::NTR : 1];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { th[i] = (double)x[i]; z[i] = (double)y[i]; }
+  th[12] = (double)u[0]; th[13] = (double)u[1]; th[14] = (double)u[2]; th[15] = h;
+  MD::eval_pre(th, pre);
+  MD::eval_r(z, th, pre, tr, r);
+  typename MD::template Fact<double> f;
+  const bool ok = eval_factor<MD>(z, th, pre, tr, 0.0, f);
+  MD::solve(f, r, D);
+#pragma unroll
+  for (int i = 0; i < MD::NZ; ++i) { z[i] -= D[i]; y[i] = (float)z[i]; }
+  if (want_grad) {
+    // (the factorisation of the point before the step: the Jacobian moves by the size of the step, ~1e-6 relative)
+    double g[MD::NNZTH];
+    MD::eval_rth(z, th, pre, tr, g);
+    for (int c = 0; c < MD::NGC; ++c) {
+      double b[MD::NZ];
+#pragma unroll
+      for (int i = 0; i < MD::NZ; ++i) b[i] = 0.0;
+#pragma unroll
+      for (int k = 0; k < MD::NNZTH; ++k) b[MD::RTH_ROW[k]] = (MD::RTH_COL[k] == c) ? g[k] : b[MD::RTH_ROW[k]];
+      MD::solve(f, b, b);
+#pragma unroll
+      for (int i = 0; i < MD::NZQ; ++i) sink.grad(i, c, -b[MD::ZQ[i]]);
+    }
+  }
+  return ok;
+}
+
+// The same refinement where only the state is wanted (the rollout kernels, 60 sequential knots per trajectory): the residual in
+// double at the single-precision solution, the correction through the SINGLE-precision factors the Newton iteration left behind
+// (mixed-precision iterative refinement: the error contracts by |J_float^{-1} J - I| ~ 1e-3 per step, from ~1e-6 to ~1e-9) -- one
+// residual evaluation in double and one float back-solve instead of a double factorisation.
+template <class MD, class F32> OD_HD void rocket_refine64(const float* x, const float* u, double h, const float* th32, float* y, F32& f, bool have_fact) {
+  double th[MD::NTH], z[MD::NZ], r[MD::NZ], pre[MD::NPRE > 0 ? MD::NPRE : 1], tr[MD::NTR > 0 ? MD::NTR : 1];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { th[i] = (double)x[i]; z[i] = (double)y[i]; }
+  th[12] = (double)u[0]; th[13] = (double)u[1]; th[14] = (double)u[2]; th[15] = h;
+  MD::eval_pre(th, pre);
+  MD::eval_r(z, th, pre, tr, r);
+  float rf[MD::NZ], D[MD::NZ];
+#pragma unroll
+  for (int i = 0; i < MD::NZ; ++i) rf[i] = (float)r[i];
+  if (!have_fact) {           // (the float iteration converged at its starting point: nothing factorised yet)
+    float pre32[MD::NPRE > 0 ? MD::NPRE : 1], tr32[MD::NTR > 0 ? MD::NTR : 1], r32[MD::NZ];
+    MD::eval_pre(th32, pre32);
+    MD::eval_r(y, th32, pre32, tr32, r32);
+    eval_factor<MD>(y, th32, pre32, tr32, 0.0f, f);
+  }
+  MD::solve(f, rf, D);
+#pragma unroll
+  for (int i = 0; i < MD::NZ; ++i) y[i] = (float)(z[i] - (double)D[i]);
+}
+
 // one rocket knot: (x, u) in registers -> y in registers; per-knot outputs (dx, du, uproj, status) at index b
 // GRADS = false (the rollout kernels): state only -- no gradient code in the kernel at all (it would never run there, but its
 // arrays would still shape the register allocation of the time recursion)
@@ -491,7 +560,11 @@ template <class MD, class MP, class T> OD_HD void rocket_knot_state(const Rocket
   for (int i = 0; i < 12; ++i) { th[i] = x[i]; y[i] = x[i]; }
   th[12] = u[0]; th[13] = u[1]; th[14] = u[2]; th[15] = a.h;
   int it[2];
-  const int sd = ip_step_grad<MD>(a.opts_dyn, th, y, true, false, ns, it);
+  typename MD::template Fact<T> fd;
+  const int sd = ip_step_grad<MD, T, NoGradSink<T>>(a.opts_dyn, th, y, true, false, ns, it, fd);
+  if constexpr (sizeof(T) == 4) {
+    if (a.polish64) rocket_refine64<MD>(x, u, a.h64, th, y, fd, it[0] > 0);
+  }
   st |= (sd & (OD_ST_EVAL_OK | OD_ST_FACTOR_OK));
   if (a.status.ok()) a.status.at(0, b) = st;
 }
@@ -526,7 +599,20 @@ OD_HD void rocket_knot(const RocketArgs<T>& a, long b, const T* x, T* u, T* y) {
 #pragma unroll
   for (int i = 0; i < 36; ++i) dyn_u[i] = T(0);
   int it[2];
-  const int sd = ip_step_grad<MD>(a.opts_dyn, th, y, true, a.want_grad != 0, ds, it);
+  int sd;
+  if constexpr (sizeof(T) == 4) {
+    if (a.polish64) {
+      NoGradSink<T> ns;
+      sd = ip_step_grad<MD>(a.opts_dyn, th, y, true, false, ns, it);
+      CastSink64<RocketDynSink<T>> cs{ds};
+      if (!rocket_polish64<MD>(x, u, a.h64, y, a.want_grad != 0, cs)) sd &= ~OD_ST_FACTOR_OK;
+      if (a.want_grad && (sd & OD_ST_EVAL_OK)) sd |= OD_ST_GRAD_OK;
+    } else {
+      sd = ip_step_grad<MD>(a.opts_dyn, th, y, true, a.want_grad != 0, ds, it);
+    }
+  } else {
+    sd = ip_step_grad<MD>(a.opts_dyn, th, y, true, a.want_grad != 0, ds, it);
+  }
   st |= (sd & 7);
   if (a.want_grad && a.du.ok()) {
 #pragma unroll

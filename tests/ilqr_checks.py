@@ -244,6 +244,17 @@ def check_rocket_ilqr(oracle, lib, device, B=4, T=20, dtype=torch.float64):
     # rollout == chained f_rocket_proj of the oracle, in either precision
     X, A, Bm, st, _, _ = dyn.rollout(x1t, Ut)
     check_rollout_against_oracle(oracle, dyn, x1, U0, X, A, Bm, dtype, ntraj=min(B, 2))
+    # the time recursion without the projection (no path dependence at all): every step of the device's rollout against the
+    # oracle's f_rocket from the device's own previous state -- 1e-6 in both precisions (single: the double-precision residual
+    # refinement of the rollout kernels, csrc/od_units.h::rocket_refine64)
+    from optimization_dynamics_amd import rocket as rk
+    Xn, Un, sn = rk._rocket_rollout(dyn.info, x1t, Ut, False)
+    Xn = Xn.double().cpu().numpy()
+    Uq = U0.astype(np.float32).astype(np.float64) if dtype == torch.float32 else U0
+    for b in range(min(B, 2)):
+        for t in range(T):
+            ok, y, dz, it = oracle.rocket(0.05, Xn[:, t, b], Uq[:, t, b], False)
+            assert np.abs(Xn[:, t + 1, b] - y).max() < 1e-6 * max(1, np.abs(y).max()), (dtype, b, t, np.abs(Xn[:, t + 1, b] - y).max())
     solver = IL.ILQR(dyn, obj, T)
     J0 = obj.value(X, Ut.double())
     Xs, Us, J, hist = solver.solve(x1t, Ut, max_iter=10)
