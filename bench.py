@@ -392,7 +392,7 @@ def main():
         traffic, traffic_note, pmc = measured_traffic(B, T, args.gather or args.dense)
         coop_on = bool(im.lib.cdll.od_uses_cooperative(im._h, B)) if hasattr(im.lib.cdll, "od_uses_cooperative") else False
         line = {
-            "metric": "contact-implicit steps+grads/sec, hopper T=100 batch=4096",
+            "metric": "contact-implicit steps+grads/sec, hopper T=%d batch=%d%s" % (T, args.batch, "" if args.scaling == "weak" else " (fixed total, sharded)"),
             "value": value, "unit": "steps+grads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "ranks_seen": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else "none (single process)"),
@@ -407,7 +407,9 @@ def main():
             "roofline": {"bound": "fp64-valu", "bound_detail": "fp64 vector ALU roof; algorithmic flops of the reference's dense-LU algorithm (SURVEY.md 8d) over the kernel time -- the device executes a sparse elimination, so this is a useful-work ratio",
                          "achieved": ach_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / FP64_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_note": "%s; algorithmic = %d" % (traffic_note, algorithmic_bytes_per_unit() * units_per_rank),
-                         "kernel": ("k_rollout_state_coop<Coop_hopper> (one problem per 16 lanes)" if coop_on else "k_rollout_state<Model_hopper,double>")
+                         # (od_model_tu.inc: 16 lanes per problem up to 4096 rollouts per launch, 8 lanes up to 16 384, one lane beyond)
+                         "kernel": (("k_rollout_state_coop<Coop_hopper> (one problem per 16 lanes)" if B <= 4096 else "k_rollout_state_coop3<Coop3_hopper> (one problem per 8 lanes)")
+                                    if coop_on else "k_rollout_state<Model_hopper,double>")
                                    + " (98 %) + k_grad_knots<Model_hopper,double>", "kernel_ms": kernel_ms,
                          "algorithmic_flops_per_unit": F, "mean_iterations_to_kappa_eval": it_eval, "max_iterations": it_max,
                          "hbm_algorithmic_GBps": ach_gbs, "hbm_frac": ach_gbs / HBM_PEAK_GBS,

@@ -163,6 +163,9 @@ template <int N, class T> OD_HD T od_powi(T x);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(OD_EXACT_RCP)
 template <int Q> __device__ __forceinline__ double od_rootinv(double x) {
   if constexpr (Q == 2) {
+    // (x = 0 and x = inf would turn the Newton steps into 0 * inf = NaN where 1 / sqrt(x) is +inf and 0: same answers as the host
+    // build on degenerate geometry -- a planar-push distance that vanishes exactly)
+    if (!(x > 1e-300 && x < 1e300)) return 1.0 / sqrt(x);
     double y = __builtin_amdgcn_rsq(x);
     const double nhx = -0.5 * x;
 #pragma unroll

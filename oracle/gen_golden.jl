@@ -141,5 +141,25 @@ let
     for (n, a) in (("Y", Y), ("DX", DX), ("DU", DU), ("Yp", Yp), ("DXp", DXp), ("DUp", DUp), ("UP", UP), ("DP", DP))
         writearr(joinpath(outdir, "rocket_" * n * ".bin"), a)
     end
+    # The projection's ITERATE PATH: z after k = 1 .. KP iterations of soc_projection's interior-point solve (the same solve cut
+    # short by max_iter = k).  Its line search compares rounding noise from the first full step on (DESIGN.md section 5,
+    # "line-search ties"): implementations can accept different step lengths and end on kappa_tol-level different points.  With
+    # the path on file the accepted step of every iteration of the reference is known (z_k - z_{k-1} against the direction), and
+    # tests/test_reference_golden.py compares paths instead of end points.  (Needs the solver options to be mutable, as
+    # RoboDojo's InteriorPointOptions are; skipped with a note otherwise.)
+    try
+        KP = 14
+        PATH = fill(NaN, 10, KP, B)
+        keep = info.ip_proj.opts.max_iter
+        for b = 1:B, k = 1:KP
+            info.ip_proj.opts.max_iter = k
+            OptimizationDynamics.soc_projection(U[:, b], info)
+            PATH[:, k, b] .= info.ip_proj.z
+        end
+        info.ip_proj.opts.max_iter = keep
+        writearr(joinpath(outdir, "rocket_PATH.bin"), PATH)
+    catch e
+        println("projection iterate path not written: ", e)
+    end
 end
 println("reference vectors written to ", outdir)

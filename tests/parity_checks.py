@@ -53,6 +53,25 @@ def assert_grad_close(G, Go, ok, what):
 EXACT_TOL = 1e-8
 
 
+def assert_grad_conditioned(oracle, im, name, X, U, Ga, Gb, ok, what):
+    """two device kernels that run the same arithmetic in two compilations (a fused launch against the two-pass path): held to
+    the binary128 arbiter at the iterate the two-pass path recorded (`im`'s LAST step_grad* call must be that path on (X, U)) --
+    both within max(1e-8, cond * 1e-13) of the exact gradient there, cond = ||rz|| ||rz^-1|| from the arbiter: a knot may
+    disagree only as far as its own conditioning explains (1e-5 at cond = 1e8)"""
+    B = X.shape[1]
+    sim = make_sim(oracle, name)
+    Zd = im.grad_iterates(B).cpu().numpy()
+    E, cond = oracle.arbiter_dq3(sim, X, U, Zd)
+    sc = np.maximum(np.abs(E).reshape(-1, B).max(0), 1e-12)
+    fin = ok & np.isfinite(cond) & np.isfinite(sc)
+    bound = np.maximum(EXACT_TOL, cond * 1e-13)
+    for tag, G in (("two-pass", Ga), ("fused", Gb)):
+        e = np.abs(G - E).reshape(-1, B).max(0) / sc
+        assert (e[fin] <= bound[fin]).all(), (what, tag, (e[fin] / bound[fin]).max())
+    d = np.abs(Ga - Gb).reshape(-1, B).max(0) / sc
+    assert np.median(d[fin]) < 1e-9 and (d[fin] <= 2 * bound[fin]).all()
+
+
 def exact_gradient_errors(oracle, im, name, X, U, Gd, Zd=None):
     """Gd: (nq, 2nq+nu, B) = the device's dq3/d(q1,q2,u1) of the LAST step_grad call on `im` for (X, U).
     -> dict of per-knot relative errors (scale = max |exact gradient| of the knot):
@@ -200,9 +219,8 @@ def check_rollout(oracle, lib, device, B, T, name="hopper", u_sigma=0.3):
     assert torch.equal(D, X[:, t + 1])
     # the split rollout differentiates in a second pass (same iterate, same clamp): identical up to
     # the compiler's instruction scheduling / FMA contraction of the two kernels
-    okk = ((st1 & 3) == 3).cpu().numpy()
-    assert_grad_close(np.concatenate([A[:, :, t].cpu().numpy(), Bm[:, :, t].cpu().numpy()], 1),
-                      np.concatenate([DX.cpu().numpy(), DU.cpu().numpy()], 1), okk, "rollout vs step_grad")
+    # the split rollout differentiates in the SAME second-pass kernel on the same recorded iterates: bit for bit
+    assert torch.equal(A[:, :, t], DX) and torch.equal(Bm[:, :, t], DU), "rollout vs step_grad"
     # gradients along the trajectory vs the oracle on the oracle's states (first knots)
     G = np.concatenate([An[:, :, 0], Bn[:, :, 0]], 1)
     Go = np.concatenate([Ao[:, :, 0], Bo[:, :, 0]], 1)
@@ -252,13 +270,31 @@ def check_bundle(oracle, lib, device, name, B, N):
         if not (ok and st[b] == 1 and sampled.all()):
             continue
         assert np.abs(dz[:, :, b] - dzo).max() < 10 * (1e-8 / 1e-4) * max(1.0, np.abs(dzo).max())
-    # the bundle approximates the analytic implicit gradient (smooth branch): sanity, loose
-    D, DX, DU, st2, it = im.step_grad(torch.tensor(X), torch.tensor(U))
+    # the bundle against the analytic implicit gradient OF THE SAME SOLUTION MAP: the bundle differences eval-simulator steps
+    # (kappa_eval), so the analytic gradient is taken at kappa_grad = kappa_eval here.  A least-squares fit of one-coordinate
+    # differences over a cloud of radius eps returns an average of the gradient over that cloud, so on EVERY converged knot it
+    # must lie within the variation of the analytic gradient across the cloud (measured: the analytic gradient at perturbations
+    # of 3 eps, four draws) plus 2 % for truncation and solver noise (r_tol / eps summed over the samples); where the map is smooth
+    # at that scale (variation < 1 %) that is a 2 % bound outright, and the median over all knots is below 1 %.
+    ims = make_im(name, lib, device)
+    ims.set_options(kappa_grad_tol=W.CONFIGS[name][1])
+    D, DX, DU, st2, it = ims.step_grad(torch.tensor(X), torch.tensor(U))
     G = np.concatenate([DX.cpu().numpy()[nq:], DU.cpu().numpy()[nq:]], 1)
     good = (st == 1) & ((st2.cpu().numpy() & 3) == 3)
     if sampled.all() and good.any():
-        rel = np.abs(dz - G).reshape(-1, B).max(0) / np.maximum(1.0, np.abs(G).reshape(-1, B).max(0))
-        assert (rel[good] < 0.2).mean() >= 0.25          # (knots next to a mode switch differ by design: the bundle smooths)
+        rng = np.random.default_rng(5)
+        sc = np.maximum(1.0, np.abs(G).reshape(-1, B).max(0))
+        var = np.zeros(B)
+        for _ in range(4):
+            dX, dU = 3 * gb.eps * rng.normal(size=X.shape), 3 * gb.eps * rng.normal(size=U.shape)
+            _, DXp, DUp, stp, _ = ims.step_grad(torch.tensor(X + dX), torch.tensor(U + dU))
+            Gp = np.concatenate([DXp.cpu().numpy()[nq:], DUp.cpu().numpy()[nq:]], 1)
+            good &= (stp.cpu().numpy() & 3) == 3
+            var = np.maximum(var, np.abs(Gp - G).reshape(-1, B).max(0) / sc)
+        rel = np.abs(dz - G).reshape(-1, B).max(0) / sc
+        assert good.mean() > 0.5
+        assert (rel[good] <= 2e-2 + var[good]).all(), (rel[good] - var[good]).max()
+        assert np.median(rel[good]) < 1e-2, np.median(rel[good])
     # reference-signature wrappers
     b = 0
     dx = np.zeros((2 * nq, 2 * nq)); du = np.zeros((2 * nq, m.nu))
@@ -464,7 +500,7 @@ def check_step_full(oracle, lib, device, name, B=96):
     assert ok.mean() > 0.9 and np.array_equal(st, st2.cpu().numpy()) and torch.equal(it, it2)
     # the fused launch and the two-pass path are different kernels of the same arithmetic
     assert np.abs(Z[:nq] - D.cpu().numpy()[nq:])[:, ok].max() < 1e-10
-    assert_grad_close(DZ[:nq], G.cpu().numpy(), ok, "step_full q rows vs step_grad_compact")
+    assert_grad_conditioned(oracle, im, name, X, U, G.cpu().numpy(), DZ[:nq], ok, "step_full q rows vs step_grad_compact")
     if ix["gamma"]:
         assert (Z[ix["gamma"]][:, ok] >= 0).all()                      # impulses are interior-point iterates: never negative (an inactive one may round to 0)
     sim = make_sim(oracle, name)
@@ -561,7 +597,7 @@ def check_ip_solve(oracle, lib, device, dtype=torch.float64):
     ok = ((st & 3) == 3).cpu().numpy()
     assert ok.mean() > 0.95
     assert (z[:2] - Q3).abs().cpu().numpy()[:, ok].max() < 1e-9
-    assert_grad_close(dz.cpu().numpy()[:, :5], G.cpu().numpy(), ok, "raw solve vs step_grad")
+    assert_grad_conditioned(oracle, im, name, Xk, Uk, G.cpu().numpy(), dz.cpu().numpy()[:, :5], ok, "raw solve vs step_grad")
 
 
 def check_live_setters(lib, device):
@@ -730,8 +766,7 @@ def check_rollout_instantiation(oracle, lib, device, B, T, B_ref, n_oracle=256, 
         t = min(t, T - 1)
         Q3, Gs, s1, i1 = im.step_grad_compact(X[:, t].contiguous(), Ud[:, t].contiguous())
         assert torch.equal(Q3, X[4:, t + 1]) and torch.equal(s1, st[t]) and torch.equal(i1, it[:, t]), t
-        okk = ((s1 & 3) == 3).cpu().numpy()
-        assert_grad_close(G[:, :, t].cpu().numpy(), Gs.cpu().numpy(), okk, "rollout vs chained step, knot %d" % t)
+        assert torch.equal(G[:, :, t], Gs), "rollout vs chained step, knot %d: same second-pass kernel, same recorded iterates" % t
     # the other mapping, batch by batch
     for b0 in range(0, B, B_ref):
         b1 = min(B, b0 + B_ref)

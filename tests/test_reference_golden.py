@@ -171,6 +171,41 @@ def _oracle_rocket(oracle):
 
 
 @have_ref
+def test_projection_iterate_path_matches_julia_reference(oracle, emu_lib):
+    """rocket_PATH.bin (oracle/gen_golden.jl): the reference's projection iterate after k = 1..14 iterations.  Up to the first
+    iteration at which the reference's line search backtracked the iterates are a deterministic function of the algorithm
+    (every implementation accepts the full step there): the oracle and the library's raw solver (od_ip_solve on the
+    rocket_projection model, max_iter = k) must reproduce them to 1e-9; this is what pins the recalled interior-point loop
+    (centering rule, step-length rule, 0.99 cone cap) one iteration at a time, and the first k where they part names the rule
+    that differs.  Past a backtracking iteration the paths may legitimately fork (rounding-level ties)."""
+    if not os.path.exists(os.path.join(REF, "rocket_PATH.bin")):
+        pytest.skip("no projection iterate path in this set of vectors")
+    import export_inputs as E
+    from optimization_dynamics_amd import interior_point as IP
+    X, U = E.rocket_case()
+    B = U.shape[1]
+    PATH = ref("rocket_PATH", (10, 14, B))
+    z0 = np.array([0.1, 0.1, 1.1, 0.1, 0.1, 0.1, 0.0, 0.1, 0.1, 1.1])
+    th = torch.tensor(np.vstack([U, np.full((1, B), 12.5)]))
+    forked = np.zeros(B, bool)
+    for k in range(1, 15):
+        ip = IP.InteriorPoint("rocket_projection", device="cpu", lib=emu_lib, options=dict(max_iter=k))
+        z, _, st, it = ip.solve(torch.tensor(np.tile(z0[:, None], (1, B))), th, diff_sol=False)
+        z = z.numpy()
+        err = np.abs(z - PATH[:, k - 1]).max(0) / np.maximum(1.0, np.abs(PATH[:, k - 1]).max(0))
+        new_fork = (err > 1e-9) & ~forked
+        # a fork is legitimate only from an iteration whose step was shortened by the line search in the reference: the
+        # reference's own step from z_{k-1} to z_k is then shorter than the step to the boundary; without the direction on file
+        # this is reported, not asserted, beyond the first three iterations (which are far from any tie)
+        if k <= 3:
+            assert not new_fork.any(), (k, err.max())
+        forked |= new_fork
+        if new_fork.any():
+            print("projection path: %d of %d controls part from the reference at iteration %d (max %.2e)" % (int(new_fork.sum()), B, k, err.max()))
+    assert forked.mean() < 0.5
+
+
+@have_ref
 @pytest.mark.parametrize("name", ["cartpole_friction", "hopper", "planar_push"])
 def test_oracle_bundle_matches_julia_reference(oracle, name):
     if not os.path.exists(os.path.join(REF, "bundle_%s_DZ.bin" % name)):
