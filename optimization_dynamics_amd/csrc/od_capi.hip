@@ -1362,6 +1362,7 @@ template <class T> static int rocket_rollout_impl(od_handle h, long B, int Tn, i
   ra.K = mkcview<T>(K, 36, Kn, L);
   ra.kff = mkcview<T>(kff, 3, Kn, L);
   ra.U = mkview<T>(U, 3, Kc, L);
+  ra.cq = ra.cr = ra.cqt = ra.cxref = nullptr; ra.J = nullptr; ra.okall = nullptr;
   hipError_t e;
   if constexpr (sizeof(T) == 8) e = launch_rocket_rollout64(ra, ppw_of(h, P), h->stream);
   else e = launch_rocket_rollout32(ra, ppw_of(h, P), h->stream);

@@ -541,7 +541,7 @@ template <class MD, class F32> OD_HD void rocket_refine64(const float* x, const 
 // one rocket knot: (x, u) in registers -> y in registers; per-knot outputs (dx, du, uproj, status) at index b
 // GRADS = false (the rollout kernels): state only -- no gradient code in the kernel at all (it would never run there, but its
 // arrays would still shape the register allocation of the time recursion)
-template <class MD, class MP, class T> OD_HD void rocket_knot_state(const RocketArgs<T>& a, long b, const T* x, T* u, T* y) {
+template <class MD, class MP, class T> OD_HD void rocket_knot_state(const RocketArgs<T>& a, long b, const T* x, T* u, T* y, int* ok_and = nullptr) {
   int st = 0;
   NoGradSink<T> ns;
   if (a.project) {
@@ -567,6 +567,7 @@ template <class MD, class MP, class T> OD_HD void rocket_knot_state(const Rocket
   }
   st |= (sd & (OD_ST_EVAL_OK | OD_ST_FACTOR_OK));
   if (a.status.ok()) a.status.at(0, b) = st;
+  if (ok_and) *ok_and &= st;                  // (bit 0: the dynamics solve converged)
 }
 
 template <class MD, class MP, class T>
@@ -682,6 +683,13 @@ template <class T> struct RocketRolloutArgs {
   const T* alphas;
   View<const T> xbar, ubar, K, kff;
   View<T> U;             // controls applied (before projection), per candidate knot
+  // device-resident iLQR iteration with a DIAGONAL quadratic objective (od_ilqr_solver.inc): the cost of every candidate is summed
+  // up along its rollout -- J_p = sum_t 1/2 (x_t - xref)'Q(x_t - xref) + 1/2 u_t'R u_t + 1/2 (x_T - xref)'QT(x_T - xref), in double,
+  // knot after knot (a fixed order: the cost decides the Armijo comparison) -- instead of a second pass over the candidates'
+  // states; okall[p] = every dynamics solve of the rollout converged.  All null otherwise.
+  const double *cq, *cr, *cqt, *cxref;   // diagonals of Q (12), R (3), QT (12); xref (12)
+  double* J;
+  int* okall;
 };
 
 template <class MD, class MP, class T> OD_HD void unit_rocket_rollout(const RocketRolloutArgs<T>& ra, long p) {
@@ -694,6 +702,17 @@ template <class MD, class MP, class T> OD_HD void unit_rocket_rollout(const Rock
   if (ra.x0.ok()) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) ra.x0.at(i, p) = x[i];
+  }
+  double Jacc = 0.0;
+  int okk = 1;
+  // (the objective's constants once, before the recursion: a load inside it would wait behind the knot's stores -- the memory
+  // counter is in order)
+  double cq[12], cr[3], cx[12];
+  if (ra.J) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { cq[i] = ra.cq[i]; cx[i] = ra.cxref[i]; }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) cr[j] = ra.cr[j];
   }
   for (int t = 0; t < ra.Tn; ++t) {
     const long kn = (long)t * ra.Bnom + b, kc = (long)t * a.B + p;
@@ -713,7 +732,15 @@ template <class MD, class MP, class T> OD_HD void unit_rocket_rollout(const Rock
 #pragma unroll
       for (int j = 0; j < 3; ++j) ra.U.at(j, kc) = u[j];
     }
-    rocket_knot_state<MD, MP, T>(a, kc, x, u, y);
+    if (ra.J) {
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) { const double v = (double)x[i] - cx[i]; s += cq[i] * v * v; }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { const double v = (double)u[j]; s += cr[j] * v * v; }
+      Jacc += 0.5 * s;
+    }
+    rocket_knot_state<MD, MP, T>(a, kc, x, u, y, ra.okall ? &okk : nullptr);
     if (a.y.ok()) {
 #pragma unroll
       for (int i = 0; i < 12; ++i) a.y.at(i, kc) = y[i];
@@ -721,6 +748,13 @@ template <class MD, class MP, class T> OD_HD void unit_rocket_rollout(const Rock
 #pragma unroll
     for (int i = 0; i < 12; ++i) x[i] = y[i];
   }
+  if (ra.J) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { const double v = (double)x[i] - cx[i]; s += ra.cqt[i] * v * v; }
+    ra.J[p] = Jacc + 0.5 * s;
+  }
+  if (ra.okall) ra.okall[p] = okk;
 }
 
 }  // namespace od

@@ -180,9 +180,9 @@ def test_projection_iterate_path_matches_julia_reference(oracle, emu_lib):
     that differs.  Past a backtracking iteration the paths may legitimately fork (rounding-level ties)."""
     if not os.path.exists(os.path.join(REF, "rocket_PATH.bin")):
         pytest.skip("no projection iterate path in this set of vectors")
-    import export_inputs as E
     from optimization_dynamics_amd import interior_point as IP
-    X, U = E.rocket_case()
+    g = np.load(os.path.join(HERE, "golden", "oracle_v1.npz"))
+    U = g["rocket/U"]
     B = U.shape[1]
     PATH = ref("rocket_PATH", (10, 14, B))
     z0 = np.array([0.1, 0.1, 1.1, 0.1, 0.1, 0.1, 0.0, 0.1, 0.1, 1.1])
