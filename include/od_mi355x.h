@@ -85,8 +85,11 @@ int od_set_u_max(od_handle h, double u_max);
 /* The thrust-cone projection (soc_projection, src/models/rocket/dynamics.jl:168-186, eps_min = 0) can stall on the boundary of the
  * cone away from the solution -- accepted step lengths ~1e-13 for the rest of its max_iter iterations, result reported as not
  * converged (status bits 16 / 32 clear), in the CPU oracle alike; ~0.02 % of random controls.  on = 1 (default): such a solve is
- * abandoned once its step length has been below 1e-9 for 4 consecutive iterations -- same status, the iterate within 1e-9 of
- * the one the full loop returns -- so that a lockstep wavefront does not wait ~90 iterations for it.  on = 0: every iteration. */
+ * abandoned once its step length has been below 1e-9 (OD_F32: 1e-5) for 4 consecutive iterations -- status bits as if max_iter
+ * had been reached -- so that a lockstep wavefront does not wait ~90 iterations for it.  A solve that does not stall is not
+ * touched (bit-identical results).  Of the stalled ones the full loop rescues about a third by accumulated rounding drift (50
+ * iterations at alpha ~ 1e-13, then convergence in three steps): with the exit they are reported as not converged instead.
+ * on = 0: every iteration, as the reference runs them. */
 int od_set_projection_stall_exit(od_handle h, int on);
 /* OD_F32 rocket handles (BASELINE config 5 asks for single precision): on = 1 (default) finishes every dynamics step with ONE
  * Newton step of the same residual in double at the single-precision solution and takes the implicit gradient -rz^{-1} rtheta

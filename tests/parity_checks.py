@@ -477,6 +477,45 @@ def check_soc_projection(oracle, lib, device, B=96):
         J[:, j] = (info.project(torch.tensor(Up), grads=False)[0].cpu().numpy()
                    - info.project(torch.tensor(Um), grads=False)[0].cpu().numpy()) / (2 * e)
     assert np.median(np.abs(J - DP).reshape(9, B).max(0)) < 5e-2
+    check_projection_stall_exit(lib, device)
+
+
+def check_projection_stall_exit(lib, device, B=40000):
+    """od_set_projection_stall_exit (csrc/od_solver.h::model_stall, DESIGN.md 3.5): a projection that has stalled on the boundary
+    of the cone -- accepted step length < 1e-9 (float: 1e-5) for 4 consecutive iterations -- is abandoned as if it had run into
+    max_iter.  (i) a solve the exit does not abandon is untouched: wherever the run WITH the exit reports convergence, result and
+    status are bit for bit those of the run without; (ii) an abandoned solve is reported as not converged; where the full loop
+    stays stalled to max_iter (most of them) its iterate is the abandoned one to 1e-8, the rest leave the stall by rounding drift
+    and either end elsewhere, still not converged, or the full loop converges on a part of
+    the stalled solves by rounding drift (50 iterations at alpha = 1.7e-13, then three full steps): their number is bounded -- they
+    are the coin flips the exit turns into reported failures; (iv) stalls are as rare as measured (0.02 % of random controls, a
+    few per cent of controls within 0.05 of the cone's apex)."""
+    rng = np.random.default_rng(11)
+    U = np.stack([rng.normal(0, 2, B), rng.normal(0, 2, B), rng.uniform(-2, 16, B)])
+    U[:, : B // 8] = rng.normal(0, 0.05, (3, B // 8))                     # around the apex (the first controls of examples/rocket.jl)
+    for dtype in (torch.float64, torch.float32):
+        info = rk.RocketInfo(models.rocket, 12.5, 0.05, dtype=dtype, device=device, lib=lib)
+        Ud = torch.tensor(U)
+        lib.check(lib.cdll.od_set_projection_stall_exit(info._h, 1))
+        UP1, DP1, st1 = info.project(Ud, grads=True)
+        lib.check(lib.cdll.od_set_projection_stall_exit(info._h, 0))
+        UP0, DP0, st0 = info.project(Ud, grads=True)
+        ok1 = (st1 & 0x30) == 0x30
+        ok0 = (st0 & 0x30) == 0x30
+        assert torch.equal(UP1[:, ok1], UP0[:, ok1]) and torch.equal(DP1[:, :, ok1], DP0[:, :, ok1]) and torch.equal(st1[ok1], st0[ok1])     # (i)
+        assert not (ok1 & ~ok0).any()
+        both_bad = (~ok1 & ~ok0)
+        near = 0
+        if both_bad.any():                                                                                                                      # (ii)
+            d = (UP1[:, both_bad] - UP0[:, both_bad]).abs().max(0).values
+            near = int((d < (1e-8 if dtype == torch.float64 else 1e-3)).sum().item())
+            assert near >= both_bad.sum().item() // 2, (near, int(both_bad.sum().item()))
+        lucky = int((~ok1 & ok0).sum().item())
+        n_stall = int((~ok1).sum().item())
+        assert lucky <= max(3, B // 1000), lucky                                                                                               # (iii)
+        assert n_stall <= B // 100, n_stall                                                                                                     # (iv)
+        print("projection stall exit, %s: %d of %d solves abandoned; without the exit %d of them converge by rounding drift, %d end within 1e-8 of the abandoned "
+              "iterate, %d leave the stall and end elsewhere, not converged either" % (str(dtype).split(".")[-1], n_stall, B, lucky, near, n_stall - lucky - near))
 
 
 def check_step_full(oracle, lib, device, name, B=96):
