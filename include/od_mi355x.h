@@ -223,6 +223,14 @@ int od_ilqr_destroy(od_ilqr s);
  * column-major, symmetric; ngoal terminal equality constraints x_T[goal_idx[i]] = goal[i] (ngoal = 0: none).  Host pointers. */
 int od_ilqr_set_objective(od_ilqr s, const double* Q, const double* R, const double* QT, const double* xref, int ngoal,
                           const int* goal_idx, const double* goal);
+/* Affine constraints handled by the augmented Lagrangian (iLQR.Constraint with idx_ineq, examples/rocket.jl:82-110,
+ * examples/planar_push.jl:105-106): stage rows  Cs x_t + Ds u_t - ds  for t < T (Cs ns x n, Ds ns x m col-major) and terminal rows
+ * Ct x_T - dt (Ct nt x n); the first ns_ineq / nt_ineq rows are inequalities (<= 0), the others equalities; ns, nt <= 16.
+ * Merit lam'c + rho/2 c'Ac with the active set A = equalities + {c_i >= 0 or lam_i > 0}; lam <- max(0, lam + rho c) on
+ * inequalities; violation = max(|c_eq|, max(c_ineq, 0)) against con_tol.  In addition to the goal rows of od_ilqr_set_objective.
+ * Host pointers; call before od_ilqr_init.  (0, 0, NULL, ...) removes them. */
+int od_ilqr_set_constraints(od_ilqr s, int ns, int ns_ineq, const double* Cs, const double* Ds, const double* ds,
+                            int nt, int nt_ineq, const double* Ct, const double* dt);
 /* initialize_controls! + rollout + first linearisation and cost (examples/acrobot.jl:108-113): x1 n per trajectory, U0 m per knot
  * (T*B knots), doubles on the device.  Resets multipliers, penalty, regularisation and counters.  Asynchronous. */
 int od_ilqr_init(od_ilqr s, const double* x1, const double* U0);
@@ -240,7 +248,11 @@ int od_ilqr_get(od_ilqr s, double* X, double* U, double* J, double* K, double* k
 /* hist: up to `cap` rows of B costs (row i = costs after iteration i), device pointer; returns the number of rows kept so far
  * (synchronises) or a negative error */
 int od_ilqr_get_history(od_ilqr s, double* hist, int cap);
-int od_ilqr_get_info(od_ilqr s, od_ilqr_info* out);   /* synchronises the handle's stream */
+/* per trajectory (device pointers, any may be NULL; asynchronous): flags (bit 0: inner loop converged, bit 1: constraints met to
+ * con_tol), violation as of the last od_ilqr_al_update / od_ilqr_solve, penalty rho.  The B problems are independent solves: each
+ * has its own regularisation schedule, penalty and flags, and follows the path it would follow in a batch of one. */
+int od_ilqr_get_status(od_ilqr s, int* flags, double* violation, double* penalty);
+int od_ilqr_get_info(od_ilqr s, od_ilqr_info* out);   /* synchronises the handle's stream; done / al_done: every trajectory's flag; reg, rho: the largest */
 
 /* gradient! (src/gradient_bundle.jl:87-104) for B knots: N+1 eval-simulator steps per knot with the
  * caller's perturbations eta ((2nq+nu) x N col-major, shared by all knots; the reference draws them

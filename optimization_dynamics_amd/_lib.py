@@ -86,12 +86,15 @@ SIGNATURES = {
     "od_ilqr_create": (C.c_int, [_VP, C.c_long, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(IlqrOptions), C.POINTER(_VP)]),
     "od_ilqr_destroy": (C.c_int, [_VP]),
     "od_ilqr_set_objective": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "od_ilqr_set_constraints": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "od_ilqr_init": (C.c_int, [_VP, _VP, _VP]),
     "od_ilqr_iterate": (C.c_int, [_VP, C.c_int]),
     "od_ilqr_al_update": (C.c_int, [_VP]),
     "od_ilqr_solve": (C.c_int, [_VP, _VP, _VP]),
     "od_ilqr_get": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "od_ilqr_get_history": (C.c_int, [_VP, _VP, C.c_int]),
+    "od_ilqr_get_status": (C.c_int, [_VP, _VP, _VP, _VP]),
     "od_ilqr_get_info": (C.c_int, [_VP, C.POINTER(IlqrInfo)]),
     "od_bundle_workspace_bytes": (C.c_size_t, [_VP, C.c_long, C.c_int]),
     "od_bundle_grad": (C.c_int, [_VP, C.c_long, C.c_int, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _IP]),

@@ -220,7 +220,8 @@ template <class TA> struct IlqrArgsT {
   View<double> dV;                                   // per trajectory: [sum k'Qu, sum 0.5 k'Quu k]
   View<int> status;                                  // per trajectory: 1 = every Quu factorised (positive pivots)
   // device-resident iteration (all null / 0 for od_ilqr_backward):
-  const double* reg_dev;                             // regularisation read from device memory instead of `reg`
+  const double* reg_dev;                             // regularisation per trajectory, read from device memory instead of `reg`
+  const int* done_b;                                 // (may be null) per trajectory: non-zero = nothing to do for it
   int retry;                                         // 1: a trajectory whose Quu + reg I is not positive definite repeats ITS recursion with
                                                      // reg <- min(max(reg, 1e-8) * 10, 1e6) until it factorises; still failing at 1e6: K = k = dV = 0, status 0
   const int* skip;                                   // *skip != 0: the launch does nothing
@@ -247,7 +248,8 @@ template <class TA> __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_back
   // entry owned by this thread in n x n, n x m (rows n) and m x n (rows m) matrices
   const int in_ = tid % n, jn_ = tid / n;         // valid if tid < nn (n x n) or tid < nm (n x m: column jn_ < m)
   const int im_ = tid % m, jm_ = tid / m;         // valid if tid < nm (m x n: column jm_ < n) or tid < mm (m x m)
-  double reg = a.reg_dev ? *a.reg_dev : a.reg;
+  if (a.done_b && a.done_b[b]) return;
+  double reg = a.reg_dev ? a.reg_dev[b] : a.reg;
   for (;;) {                                  // (one pass unless a.retry)
   if (tid < nn) Vxx[tid] = a.VxxT.at(tid, b);
   if (tid < n) Vx[tid] = a.VxT.at(tid, b);
@@ -876,7 +878,8 @@ __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward_row(IlqrArgsT<T
   const int ir = i < N ? i : N - 1, im = i < M ? i : M - 1;       // (lanes without a row repeat the last one)
   double Vr[N], vx, dV0, dV1;
   int okf;
-  double reg = a.reg_dev ? *a.reg_dev : a.reg;
+  if (a.done_b && a.done_b[bb]) return;       // (the whole row leaves: its lanes share nothing with the other rows)
+  double reg = a.reg_dev ? a.reg_dev[bb] : a.reg;
   // (one pass unless a.retry: a row whose Quu + reg I fails to factorise repeats its own recursion at a larger reg while the
   // other rows of the wavefront wait -- the rows share nothing but the instruction stream)
   for (;;) {
@@ -1037,7 +1040,8 @@ template <class TA> __global__ __launch_bounds__(OD_BLOCK) void k_ilqr_backward_
   double Vxx[OD_IL_N * OD_IL_N], Vx[OD_IL_N], At[OD_IL_N * OD_IL_N], Bt[OD_IL_N * OD_IL_M], W[OD_IL_N * OD_IL_N];
   double Qxx[OD_IL_N * OD_IL_N], Quu[OD_IL_M * OD_IL_M], Qux[OD_IL_M * OD_IL_N], Qx[OD_IL_N], Qu[OD_IL_M];
   double L[OD_IL_M * OD_IL_M], Kt[OD_IL_M * OD_IL_N], kt[OD_IL_M];
-  double dV1, dV2, reg = a.reg_dev ? *a.reg_dev : a.reg;
+  if (a.done_b && a.done_b[b]) return;
+  double dV1, dV2, reg = a.reg_dev ? a.reg_dev[b] : a.reg;
   bool ok;
   for (;;) {
   for (int i = 0; i < n * n; ++i) Vxx[i] = a.VxxT.at(i, b);
@@ -1655,7 +1659,7 @@ int od_rollout_policy(od_handle h, long B, int T, int nalpha, const void* alphas
   pa.K = mkcview<double>(K, nu * n, Kn, L);
   pa.kff = mkcview<double>(kff, nu, Kn, L);
   pa.U = mkview<double>(U, nu, Kc, L);
-  pa.skip = nullptr;
+  pa.skip = nullptr; pa.live = nullptr; pa.live_mod = 1;
   OD_HIP(h->vt->rollout_policy(pa, cfg_of(h, P), h->stream));
   return OD_OK;
 }
@@ -1678,7 +1682,7 @@ int od_ilqr_backward(od_handle h, long B, int T, int n, int m, const void* A, co
   a.VxxT = mkcview<double>(VxxT, n * n, B, L); a.VxT = mkcview<double>(VxT, n, B, L);
   a.K = mkview<double>(K, m * n, Kn, L); a.k = mkview<double>(k, m, Kn, L);
   a.dV = mkview<double>(dV, 2, B, L); a.status = mkview<int>(status, 1, B, L);
-  a.reg_dev = nullptr; a.retry = 0; a.skip = nullptr;
+  a.reg_dev = nullptr; a.retry = 0; a.skip = nullptr; a.done_b = nullptr;
 #if defined(__HIPCC__)
   {
     // batch-minor data: TB consecutive trajectories per workgroup (coalesced), as many as 64 KB of LDS hold; batch-major data

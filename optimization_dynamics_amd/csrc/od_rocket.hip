@@ -38,7 +38,7 @@ hipError_t launch_soc_project32(const RocketArgs<float>& a, int ppw, hipStream_t
 template <class T> __global__ __launch_bounds__(OD_BLOCK) void k_rocket_rollout(RocketRolloutArgs<T> a, LaneMap lm) {
   if (a.a.skip && *a.a.skip) return;
   const long p = lm.problem(blockIdx.x, threadIdx.x);
-  if (lm.active(threadIdx.x) && p < a.a.B) unit_rocket_rollout<Model_rocket_dynamics, Model_rocket_projection_direct, T>(a, p);
+  if (lm.active(threadIdx.x) && p < a.a.B && (!a.a.live || a.a.live[p % a.a.live_mod])) unit_rocket_rollout<Model_rocket_dynamics, Model_rocket_projection_direct, T>(a, p);
 }
 hipError_t launch_rocket_rollout64(const RocketRolloutArgs<double>& a, int ppw, hipStream_t s) {
   hipLaunchKernelGGL((k_rocket_rollout<double>), od_grid(a.a.B, ppw), dim3(OD_BLOCK), 0, s, a, LaneMap{ppw});

@@ -235,6 +235,8 @@ template <class T> struct PolicyArgs {
   View<const T> kff;     // nu per nominal knot
   View<T> U;             // nu per candidate knot: controls actually applied
   const int* skip;       // device flag (may be null): non-zero = the launch does nothing (device-resident iLQR iteration, od_ilqr_solver.inc)
+  const int* live;       // (may be null) per nominal trajectory: candidate p is rolled out only if live[p % live_mod] != 0
+  long live_mod;
 };
 
 template <class M, class T> OD_HD void unit_rollout_policy(const PolicyArgs<T>& pa, long p) {

@@ -32,6 +32,86 @@ class QuadraticObjective:
         self.goal = None if goal is None else as_t(goal)
         self.device = dev
         self._host = {id(M): np.asarray(h, dtype=np.float64) for M, h in ((self.Q, Q), (self.R, R), (self.QT, QT))}   # (no device read-back in `expansion`)
+        self.stage = self.terminal = None
+
+    def set_constraints(self, stage=None, terminal=None):
+        """affine constraints by augmented Lagrangian (iLQR.Constraint with idx_ineq, examples/rocket.jl:82-110):
+        stage = (C (ns, n), D (ns, m), d (ns,), n_ineq):  C x_t + D u_t - d, t < T;  terminal = (C (nt, n), d (nt,), n_ineq):  C x_T - d;
+        the first n_ineq rows of each are inequalities (<= 0), the rest equalities (od_ilqr_set_constraints)"""
+        f = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+        self.stage = None if stage is None else (f(stage[0]).reshape(-1, self.n), f(stage[1]).reshape(-1, self.m), f(stage[2]).reshape(-1), int(stage[3]))
+        self.terminal = None if terminal is None else (f(terminal[0]).reshape(-1, self.n), f(terminal[1]).reshape(-1), int(terminal[2]))
+        return self
+
+    @property
+    def constrained(self):
+        return self.goal_idx is not None or self.stage is not None or self.terminal is not None
+
+    # the constraint rows, evaluated in the order of the device kernels (od_ilqr_solver.inc: sum over x then over u, then - d)
+    def stage_c(self, X, U):
+        """(ns, T, P)"""
+        C, D, d, _ = self.stage
+        out = []
+        for r in range(C.shape[0]):
+            c = torch.zeros_like(X[0, :-1])
+            for j in range(self.n):
+                c = c + float(C[r, j]) * X[j, :-1]
+            for j in range(self.m):
+                c = c + float(D[r, j]) * U[j]
+            out.append(c - float(d[r]))
+        return torch.stack(out)
+
+    def terminal_c(self, X):
+        """(nt, P)"""
+        C, d, _ = self.terminal
+        out = []
+        for r in range(C.shape[0]):
+            c = torch.zeros_like(X[0, -1])
+            for j in range(self.n):
+                c = c + float(C[r, j]) * X[j, -1]
+            out.append(c - float(d[r]))
+        return torch.stack(out)
+
+    @staticmethod
+    def _active(c, lam, n_in):
+        a = torch.ones_like(c, dtype=torch.bool)
+        a[:n_in] = (c[:n_in] >= 0) | (lam[:n_in] > 0)
+        return a
+
+    def constraint_terms(self, X, U, mult, rho):
+        """the merit's constraint terms per trajectory; mult = dict(lam=goal multipliers, lam_s=(ns, T, P), lam_t=(nt, P))"""
+        X, U = X.double(), U.double()
+        J = torch.zeros(U.shape[2], dtype=torch.float64, device=X.device)
+        if self.stage is not None:
+            c, l = self.stage_c(X, U), mult["lam_s"]
+            a = self._active(c, l, self.stage[3])
+            for t in range(c.shape[1]):                       # (the kernel's order: knot after knot, row after row)
+                for r in range(c.shape[0]):
+                    J = J + (l[r, t] * c[r, t] + torch.where(a[r, t], 0.5 * rho * c[r, t] * c[r, t], torch.zeros_like(J)))
+        if self.terminal is not None:
+            c, l = self.terminal_c(X), mult["lam_t"]
+            a = self._active(c, l, self.terminal[2])
+            for r in range(c.shape[0]):
+                J = J + (l[r] * c[r] + torch.where(a[r], 0.5 * rho * c[r] * c[r], torch.zeros_like(J)))
+        if self.goal_idx is not None:
+            c = self.constraint(X)
+            J = J + ((mult["lam"] * c).sum(0) + 0.5 * rho * (c * c).sum(0))
+        return J
+
+    def violation(self, X, U):
+        """max over all constraint rows and knots of |c_eq|, max(c_ineq, 0): (P,)"""
+        v = torch.zeros(U.shape[2], dtype=torch.float64, device=X.device)
+        if self.goal_idx is not None:
+            v = torch.maximum(v, self.constraint(X).abs().max(0).values)
+        if self.terminal is not None:
+            c = self.terminal_c(X); k = self.terminal[2]
+            c = torch.cat([c[:k].clamp_min(0.0), c[k:].abs()])
+            v = torch.maximum(v, c.max(0).values)
+        if self.stage is not None:
+            c = self.stage_c(X, U); k = self.stage[3]
+            c = torch.cat([c[:k].clamp_min(0.0), c[k:].abs()])
+            v = torch.maximum(v, c.reshape(-1, c.shape[-1]).max(0).values)
+        return v
 
     def constraint(self, X):
         """c = x_T[idx] - goal, shape (nc, P)"""
@@ -69,6 +149,8 @@ class QuadraticObjective:
                 return 0.5 * (vf * (M @ vf)).sum(0).view(-1, P).sum(0)
 
             J = quad(self.Q, dx[:, :-1]) + quad(self.R, U.double()) + quad(self.QT, dx[:, -1])
+        if isinstance(lam, dict):                               # all constraint kinds (goal rows, stage and terminal rows)
+            return J + self.constraint_terms(X, U, lam, rho)
         if self.goal_idx is not None and lam is not None:
             c = self.constraint(X)
             J = J + (lam * c).sum(0) + 0.5 * rho * (c * c).sum(0)
@@ -95,12 +177,57 @@ class QuadraticObjective:
         lux = torch.zeros(m * n, T, P, dtype=torch.float64, device=X.device)
         Vxx = self.QT.clone()[:, :, None].repeat(1, 1, P)
         Vx = matvec(self.QT, dx[:, -1])
-        if self.goal_idx is not None and lam is not None:
+        mult = lam if isinstance(lam, dict) else dict(lam=lam)
+        if self.stage is not None:
+            # (the order of il_expand_slot: w = lam + rho A c; gradients += C'w, D'w row after row; Hessians objective + rho sum (row)(row)')
+            C, D, d, k_in = self.stage
+            c, l = self.stage_c(X, U), mult["lam_s"]
+            ra = torch.where(self._active(c, l, k_in), rho * torch.ones_like(c), torch.zeros_like(c))
+            w = l + ra * c
+            ns = C.shape[0]
+            for j in range(n):
+                for r in range(ns):
+                    lx[j] = lx[j] + float(C[r, j]) * w[r]
+            for j in range(m):
+                for r in range(ns):
+                    lu[j] = lu[j] + float(D[r, j]) * w[r]
+            Qh, Rh = self._host[id(self.Q)], self._host[id(self.R)]
+            lxx = torch.empty(n * n, T, P, dtype=torch.float64, device=X.device)
+            luu = torch.empty(m * m, T, P, dtype=torch.float64, device=X.device)
+            for j in range(n):
+                for i in range(n):
+                    t_ = torch.full_like(c[0], float(Qh[i, j]))
+                    for r in range(ns):
+                        t_ = t_ + ra[r] * float(C[r, i]) * float(C[r, j])
+                    lxx[i + n * j] = t_
+            for j in range(m):
+                for i in range(m):
+                    t_ = torch.full_like(c[0], float(Rh[i, j]))
+                    for r in range(ns):
+                        t_ = t_ + ra[r] * float(D[r, i]) * float(D[r, j])
+                    luu[i + m * j] = t_
+            for j in range(n):
+                for i in range(m):
+                    t_ = torch.zeros_like(c[0])
+                    for r in range(ns):
+                        t_ = t_ + ra[r] * float(D[r, i]) * float(C[r, j])
+                    lux[i + m * j] = t_
+        if self.goal_idx is not None and mult.get("lam") is not None:
             c = self.constraint(X)
-            Vx[self.goal_idx] += lam + rho * c
+            Vx[self.goal_idx] += mult["lam"] + rho * c
             Vxx[self.goal_idx, self.goal_idx] += rho
+        if self.terminal is not None:
+            C, d, k_in = self.terminal
+            c, l = self.terminal_c(X), mult["lam_t"]
+            ra = torch.where(self._active(c, l, k_in), rho * torch.ones_like(c), torch.zeros_like(c))
+            w = l + ra * c
+            for r in range(C.shape[0]):
+                for j in range(n):
+                    Vx[j] = Vx[j] + float(C[r, j]) * w[r]
+                    for i in range(n):
+                        Vxx[i, j] = Vxx[i, j] + ra[r] * float(C[r, i]) * float(C[r, j])
         VxxT = Vxx.transpose(0, 1).reshape(n * n, P).contiguous()     # column-major flattening
-        return lxx, luu, lux, lx, lu, VxxT, Vx.contiguous()
+        return lxx, luu, lux, lx.contiguous(), lu.contiguous(), VxxT, Vx.contiguous()
 
 
 class ILQR:
@@ -197,52 +324,88 @@ class ILQR:
         return X, U, J, [h for h in hist]
 
     # -- the same loop composed from the separate entry points, decisions on the host (the checker of `solve`) -------
+    def _backward_each(self, A, Bm, quad, reg, active):
+        """backward pass with every trajectory's own regularisation (and its own retry sequence reg -> 10 reg -> ... -> 1e6, as
+        k_ilqr_backward_row does inside the kernel): od_ilqr_backward takes one reg per call, so trajectories are grouped by value.
+        -> K, k, dV, bad (never factorised: K = k = dV = 0)"""
+        n, m, T = self.n, self.m, self.T
+        B = A.shape[-1]
+        dev = self.im.device
+        K = torch.zeros(m * n, T, B, dtype=torch.float64, device=dev)
+        k = torch.zeros(m, T, B, dtype=torch.float64, device=dev)
+        dV = torch.zeros(2, B, dtype=torch.float64, device=dev)
+        todo = active.clone()
+        reg_try = reg.clone()
+        bad = torch.zeros(B, dtype=torch.bool, device=dev)
+        while todo.any():
+            for r in torch.unique(reg_try[todo]).tolist():
+                idx = (todo & (reg_try == r)).nonzero().flatten()
+                Ks, ks, dVs, bs = self.backward(A[..., idx], Bm[..., idx], tuple(q[..., idx].contiguous() for q in quad), r)
+                good = bs == 1
+                gi = idx[good]
+                K[..., gi] = Ks[..., good]; k[..., gi] = ks[..., good]; dV[:, gi] = dVs[:, good]
+                todo[gi] = False
+                fail = idx[~good]
+                give_up = fail[reg_try[fail] >= 1e6]
+                bad[give_up] = True
+                todo[give_up] = False
+                again = fail[reg_try[fail] < 1e6]
+                reg_try[again] = torch.clamp(torch.clamp(reg_try[again], min=1e-8) * 10.0, max=1e6)
+        return K, k, dV, bad
+
     def solve_stepwise(self, x1, U0, max_iter=50, max_al_iter=1, rho_init=1.0, rho_scale=10.0, con_tol=1e-3, obj_tol=1e-6, verbose=False,
                        reuse_forward_states=True):
-        """reuse_forward_states: the accepted candidate of the forward pass IS the new nominal trajectory (its states were
+        """The iteration of `solve` composed from the separate entry points with every decision taken here, on the host: the
+        checker of od_ilqr_*.  Like there, the B problems are independent solves in lockstep launches: each trajectory has its own
+        regularisation schedule, penalty, convergence flag (`done`) and constraint flag (`al_done`).
+        reuse_forward_states: the accepted candidate of the forward pass IS the new nominal trajectory (its states were
         computed by the same time recursion), so the iteration linearises on those states knot by knot instead of rolling the
         trajectory out a second time (False: the second rollout, as a check)"""
         im, obj = self.im, self.obj
         x1 = im._prep(x1)
         U = im._prep(U0).clone()
         B, na = x1.shape[-1], self.alphas.numel()
+        dev = im.device
+        z = lambda *sh: torch.zeros(*sh, dtype=torch.float64, device=dev)
+        general = obj.stage is not None or obj.terminal is not None      # stage / terminal rows: multipliers in a dict
         lam = None
-        rho = 0.0
-        if obj.goal_idx is not None:
-            lam = torch.zeros(obj.goal_idx.numel(), B, dtype=torch.float64, device=im.device)
-            rho = rho_init
+        if general:
+            lam = dict(lam=None if obj.goal_idx is None else z(obj.goal_idx.numel(), B),
+                       lam_s=None if obj.stage is None else z(obj.stage[0].shape[0], self.T, B),
+                       lam_t=None if obj.terminal is None else z(obj.terminal[0].shape[0], B))
+        elif obj.goal_idx is not None:
+            lam = z(obj.goal_idx.numel(), B)
+        rho = torch.full((B,), rho_init if lam is not None else 0.0, dtype=torch.float64, device=dev)
+        reg = torch.full((B,), float(self.reg), dtype=torch.float64, device=dev)
+        done = torch.zeros(B, dtype=torch.bool, device=dev)
+        al_done = torch.zeros(B, dtype=torch.bool, device=dev)
+
+        def rep(l):                                   # multipliers of the candidates = those of their nominal trajectory
+            if l is None:
+                return None
+            if isinstance(l, dict):
+                return {k: (None if v is None else v.repeat(*([1] * (v.dim() - 1)), na)) for k, v in l.items()}
+            return l.repeat(1, na)
+
         history = []
         X, A, Bm, st = self.linearize(x1, U)
         for al in range(max_al_iter):
             J = obj.value(X, U, lam, rho, im=im)
-            reg = float(self.reg)
             for it in range(max_iter):
+                if done.all():
+                    break
+                act = ~done
                 quad = obj.expansion(X, U, lam, rho)
-                K, k, dV, bst = self.backward(A, Bm, quad, reg)
-                # a backward pass whose Quu + reg I was not positive definite clamps its pivot and returns useless gains:
-                # raise the regularisation and repeat it before spending a forward pass on them -- for THOSE trajectories
-                # only (the batch shares `reg`, but one persistently bad trajectory, e.g. a non-finite linearisation from a
-                # failed contact solve, must not cripple the gains of the others or end the whole batch at reg = 1e6)
-                bad = (bst != 1)
-                reg_b = reg
-                while bad.any() and reg_b < 1e6:
-                    reg_b = min(max(reg_b, 1e-8) * 10.0, 1e6)
-                    idx = bad.nonzero().flatten()
-                    Ks, ks, dVs, bs = self.backward(A[..., idx], Bm[..., idx], tuple(q[..., idx].contiguous() for q in quad), reg_b)
-                    K[..., idx] = Ks; k[..., idx] = ks; dV[:, idx] = dVs
-                    bad = torch.zeros_like(bad)
-                    bad[idx[bs != 1]] = True
-                if bad.any():        # still not factorisable (non-finite data): no step for these, the line search rejects them
-                    K[..., bad] = 0.0; k[..., bad] = 0.0; dV[:, bad] = 0.0
+                K, k, dV, bad = self._backward_each(A, Bm, quad, reg, act)
                 Xc, Uc, cst = self.forward(x1, X, U, K, k)
-                Jc = obj.value(Xc, Uc, None if lam is None else lam.repeat(1, na), rho, im=im).view(na, B)
+                Jc = obj.value(Xc, Uc, rep(lam), rho.repeat(na), im=im).view(na, B)
                 ok_roll = ((cst & 1) == 1).all(0).view(na, B)
                 expected = self.alphas[:, None] * dV[0][None, :] + self.alphas[:, None] ** 2 * dV[1][None, :]
                 # (a zeroed trajectory reproduces its nominal: Jc == J and expected == 0 would pass the Armijo test -- it has no step)
-                accept = ok_roll & torch.isfinite(Jc) & (Jc <= J[None, :] + self.c1 * expected) & ~bad[None, :]
-                first = torch.where(accept.any(0), accept.float().argmax(0), torch.full((B,), -1, device=im.device, dtype=torch.long))
+                accept = ok_roll & torch.isfinite(Jc) & (Jc <= J[None, :] + self.c1 * expected) & ~bad[None, :] & act[None, :]
+                first = torch.where(accept.any(0), accept.float().argmax(0), torch.full((B,), -1, device=dev, dtype=torch.long))
                 took = first >= 0
-                sel = torch.clamp(first, min=0) * B + torch.arange(B, device=im.device)
+                sel = torch.clamp(first, min=0) * B + torch.arange(B, device=dev)
                 U = torch.where(took[None, None, :], Uc[:, :, sel].double(), U)
                 Jn = torch.where(took, Jc.reshape(-1)[sel], J)
                 dJ = (J - Jn)
@@ -255,23 +418,40 @@ class ILQR:
                         X, A, Bm, st = self.linearize(x1, U)
                         J = obj.value(X, U, lam, rho, im=im)
                 history.append(J.clone())
+                # every trajectory's own bookkeeping (k_il_finish)
+                stuck = act & ~took
+                reg = torch.where(stuck, torch.clamp(reg * 10.0, max=1e6), reg)
+                moved = act & took
+                reg = torch.where(moved, torch.clamp(reg / 5.0, min=float(self.reg)), reg)
+                done = done | (stuck & (reg >= 1e6)) | (moved & (dJ < obj_tol))
                 if verbose:
-                    print("al %d it %d  J mean %.6g  accepted %d/%d  max dJ %.3g" % (al, it, J.mean().item(), int(took.sum()), B, dJ.max().item()))
-                if not took.any():
-                    reg = min(reg * 10.0, 1e6)
-                    if reg >= 1e6:
-                        break
-                else:
-                    reg = max(reg / 5.0, self.reg)
-                if took.any() and dJ.max().item() < obj_tol:
-                    break
+                    print("al %d it %d  J mean %.6g  accepted %d/%d  converged %d  max dJ %.3g" % (al, it, J.mean().item(), int(took.sum()), B, int(done.sum()), dJ.max().item()))
             if lam is None:
                 break
-            c = obj.constraint(X)
-            if c.abs().max().item() < con_tol:
+            viol = obj.violation(X, U)
+            met = ~al_done & (viol < con_tol)
+            al_done = al_done | met
+            done = done | met
+            if al + 1 == max_al_iter or al_done.all():
                 break
-            lam = lam + rho * c
-            rho = rho * rho_scale
+            upd = ~al_done
+            if general:
+                if obj.goal_idx is not None:
+                    lam["lam"] = torch.where(upd[None, :], lam["lam"] + rho * obj.constraint(X), lam["lam"])
+                if obj.terminal is not None:
+                    l = lam["lam_t"] + rho * obj.terminal_c(X); kk = obj.terminal[2]
+                    l[:kk] = torch.where(l[:kk] > 0, l[:kk], torch.zeros_like(l[:kk]))
+                    lam["lam_t"] = torch.where(upd[None, :], l, lam["lam_t"])
+                if obj.stage is not None:
+                    l = lam["lam_s"] + rho * obj.stage_c(X, U); kk = obj.stage[3]
+                    l[:kk] = torch.where(l[:kk] > 0, l[:kk], torch.zeros_like(l[:kk]))
+                    lam["lam_s"] = torch.where(upd[None, None, :], l, lam["lam_s"])
+            else:
+                lam = torch.where(upd[None, :], lam + rho * obj.constraint(X), lam)
+            rho = torch.where(upd, rho * rho_scale, rho)
+            reg = torch.where(upd, torch.full_like(reg, float(self.reg)), reg)
+            done = torch.where(upd, torch.zeros_like(done), done)
+        self.last_status = dict(done=done, al_done=al_done, rho=rho, reg=reg)
         return X, U, J, history
 
 
@@ -305,6 +485,19 @@ class DeviceILQR:
             self.lib.check(self.lib.cdll.od_ilqr_set_objective(self._s, dp(Q), dp(R), dp(QT), dp(xr), gi.size, gi.ctypes.data_as(C.POINTER(C.c_int)), dp(g)))
         else:
             self.lib.check(self.lib.cdll.od_ilqr_set_objective(self._s, dp(Q), dp(R), dp(QT), dp(xr), 0, None, None))
+        if obj.stage is not None or obj.terminal is not None:
+            cm = lambda M: np.ascontiguousarray(M.T).reshape(-1)               # column-major flattening
+            ns = nt = nsi = nti = 0
+            Cs = Ds = ds = Ct = dt = None
+            if obj.stage is not None:
+                Cs, Ds, ds, nsi = cm(obj.stage[0]), cm(obj.stage[1]), obj.stage[2], obj.stage[3]
+                ns = obj.stage[2].size
+            if obj.terminal is not None:
+                Ct, dt, nti = cm(obj.terminal[0]), obj.terminal[1], obj.terminal[2]
+                nt = obj.terminal[1].size
+            q = lambda a: None if a is None else dp(a)
+            self._keep = (Cs, Ds, ds, Ct, dt)
+            self.lib.check(self.lib.cdll.od_ilqr_set_constraints(self._s, ns, nsi, q(Cs), q(Ds), q(ds), nt, nti, q(Ct), q(dt)))
         self.max_hist = history if history > 0 else max_iter * max_al_iter
 
     def __del__(self):
@@ -356,6 +549,16 @@ class DeviceILQR:
         self.im._use_current_stream()
         self.lib.check(self.lib.cdll.od_ilqr_get_info(self._s, C.byref(i)))
         return i
+
+    def status(self):
+        """per trajectory: flags (bit 0 inner loop converged, bit 1 constraints met), violation at the last multiplier round, penalty"""
+        dev = self.im.device
+        fl = torch.empty(self.B, dtype=torch.int32, device=dev)
+        v = torch.empty(self.B, dtype=torch.float64, device=dev)
+        r = torch.empty(self.B, dtype=torch.float64, device=dev)
+        self.im._use_current_stream()
+        self.lib.check(self.lib.cdll.od_ilqr_get_status(self._s, _ptr(fl), _ptr(v), _ptr(r)))
+        return fl, v, r
 
     def history(self):
         """(iterations, B): the costs after every iteration since init"""

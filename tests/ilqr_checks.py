@@ -350,6 +350,123 @@ def check_config5(oracle, lib, device, B=1024, iters=12):
     return hist
 
 
+def constrained_problem(lib, device, problem, B, T, dtype=torch.float64, seed=1):
+    """the problems above with affine constraints of the kinds the reference's examples pose (examples/planar_push.jl:105-106: control
+    bounds as stage inequalities; examples/rocket.jl:82-110: a state bound at every stage, a terminal box and terminal equalities)"""
+    if problem == "cartpole":
+        im, obj, x1, U0 = cartpole_problem(lib, device, B, T, seed=seed)
+        obj = IL.QuadraticObjective(obj.Q.cpu().numpy(), obj.R.cpu().numpy(), obj.QT.cpu().numpy(), obj.x_ref.cpu().numpy(), device=device)
+        n, m = 4, 1
+        # -0.45 <= u <= 0.45 (two inequality rows: active -- the unconstrained optimum pushes with 0.49), cart position x2[0] <= 0.35 (one row); terminal: |pole angle| <= 0.05 (two inequality
+        # rows on q2), cart at 0.3 (equalities on q1[0], q2[0])
+        Cs = np.zeros((3, n)); Ds = np.array([[1.0], [-1.0], [0.0]]); Cs[2, 2] = 1.0
+        ds = np.array([0.45, 0.45, 0.35])
+        Ct = np.zeros((4, n)); Ct[0, 3] = 1.0; Ct[1, 3] = -1.0; Ct[2, 0] = 1.0; Ct[3, 2] = 1.0
+        dt = np.array([0.05, 0.05, 0.3, 0.3])
+        obj.set_constraints(stage=(Cs, Ds, ds, 3), terminal=(Ct, dt, 2))
+        return im, obj, x1, U0
+    dyn, obj, x1, U0 = rocket_problem(lib, device, B, T, dtype=dtype, seed=seed)
+    n, m = 12, 3
+    Cs = np.zeros((1, n)); Cs[0, 2] = -1.0                     # length - x[3] <= 0  (examples/rocket.jl:84)
+    Ds = np.zeros((1, m)); ds = np.array([-1.0])
+    Ct = np.zeros((6, n)); dt = np.zeros(6)
+    Ct[0, 0] = -1.0; dt[0] = 0.5; Ct[1, 0] = 1.0; dt[1] = 0.5          # -0.5 <= x <= 0.5, -0.75 <= y <= 0.75 (:104-107)
+    Ct[2, 1] = -1.0; dt[2] = 0.75; Ct[3, 1] = 1.0; dt[3] = 0.75
+    Ct[4, 2] = 1.0; dt[4] = 2.0; Ct[5, 8] = 1.0; dt[5] = 0.0            # z = 2, vertical speed 0 (equalities)
+    obj.set_constraints(stage=(Cs, Ds, ds, 1), terminal=(Ct, dt, 4))
+    return dyn, obj, x1, U0
+
+
+def check_device_iteration_constrained(lib, device, problem="cartpole", B=6, T=25, dtype=torch.float64, max_iter=10, max_al_iter=4, tol=1e-9, expect_feasible=True):
+    """od_ilqr_solve with stage / terminal affine constraints (inequalities by active set) against the host-composed loop: iteration
+    counts, costs iteration by iteration, trajectories, final violation"""
+    im, obj, x1, U0 = constrained_problem(lib, device, problem, B, T, dtype=dtype)
+    x1t, Ut = torch.tensor(x1, device=device), torch.tensor(U0, device=device)
+    kw = dict(max_iter=max_iter, max_al_iter=max_al_iter, obj_tol=1e-7, con_tol=1e-4)
+    ref = IL.ILQR(im, obj, T).solve_stepwise(x1t, Ut, **kw)
+    sol = IL.ILQR(im, obj, T)
+    got = sol.solve(x1t, Ut, **kw)
+    info = sol._dev.info()
+    assert len(got[3]) == len(ref[3]) == info.iterations, (len(got[3]), len(ref[3]), info.iterations)
+    for i, (ja, jb) in enumerate(zip(got[3], ref[3])):
+        assert ((ja - jb).abs() <= tol * jb.abs().clamp(min=1.0)).all(), (problem, i, (ja - jb).abs().max().item())
+    sc = lambda t: t.abs().max().clamp(min=1.0).item()
+    assert (got[0] - ref[0]).abs().max().item() < 1e3 * tol * sc(ref[0]) and (got[1] - ref[1]).abs().max().item() < 1e3 * tol * sc(ref[1])
+    v_dev, v_ref = obj.violation(got[0], got[1]).max().item(), obj.violation(ref[0], ref[1]).max().item()
+    assert abs(v_dev - v_ref) <= 1e-6 * max(1.0, v_ref)
+    assert abs(info.max_violation - v_dev) <= 1e-12 * max(1.0, v_dev) or info.al_iterations == max_al_iter - 1      # (measured after the last round's update)
+    if expect_feasible:
+        # the multiplier rounds did their work: constraints met to con_tol where the unconstrained optimum violates them
+        assert info.al_done == 1 and v_dev < 1e-4, (info.al_done, v_dev)
+        free = IL.QuadraticObjective(obj.Q.cpu().numpy(), obj.R.cpu().numpy(), obj.QT.cpu().numpy(), obj.x_ref.cpu().numpy(), device=device)
+        Xf, Uf, _, _ = IL.ILQR(im, free, T).solve(x1t, Ut, max_iter=30, obj_tol=1e-7)
+        assert obj.violation(Xf, Uf).max().item() > 20.0 * v_dev
+    return got, ref, v_dev
+
+
+def rocket_example_problem(lib, device, B, dtype=torch.float64):
+    """examples/rocket.jl, MODE = :projection, in full: the inputs of config5_problem plus the example's constraints -- at every stage
+    length - x[3] <= 0 (:82-88), at the horizon -0.5 <= x[1] <= 0.5, -0.75 <= x[2] <= 0.75 and x[3:12] = xT[3:12] (:102-110) -- by
+    augmented Lagrangian; solver options of :123-134 (alpha_min 1e-5, obj_tol 1e-3, max_iter 100, max_al_iter 15, con_tol 0.005,
+    rho 1 x 10)"""
+    dyn, obj, x1, U0 = config5_problem(lib, device, B, dtype=dtype)
+    xT = obj.x_ref.cpu().numpy()
+    n, m = 12, 3
+    Cs = np.zeros((1, n)); Cs[0, 2] = -1.0
+    Ds = np.zeros((1, m)); ds = np.array([-1.0])
+    Ct = np.zeros((14, n)); dt = np.zeros(14)
+    Ct[0, 0] = -1.0; dt[0] = 0.5; Ct[1, 0] = 1.0; dt[1] = 0.5
+    Ct[2, 1] = -1.0; dt[2] = 0.75; Ct[3, 1] = 1.0; dt[3] = 0.75
+    for k in range(10):
+        Ct[4 + k, 2 + k] = 1.0; dt[4 + k] = xT[2 + k]
+    obj.set_constraints(stage=(Cs, Ds, ds, 1), terminal=(Ct, dt, 4))
+    opts = dict(max_iter=100, max_al_iter=15, con_tol=0.005, obj_tol=1.0e-3, rho_init=1.0, rho_scale=10.0)
+    alphas = tuple(2.0 ** -i for i in range(17))          # down to alpha_min = 1e-5
+    return dyn, obj, x1, U0, xT, opts, alphas
+
+
+def check_rocket_example(lib, device, B=1, dtype=torch.float64):
+    """the reference's rocket landing example, `:projection` mode with its constraints, solved by od_ilqr_solve: every problem reaches
+    con_tol = 0.005 (the frozen host-side ilqr_al.py needs 484 iterations / 21.8 s for one problem, examples/README.md), the thrust
+    cone holds for the applied controls (examples/rocket.jl:151), the rocket never goes below its own length"""
+    dyn, obj, x1, U0, xT, opts, alphas = rocket_example_problem(lib, device, B, dtype=dtype)
+    sol = IL.ILQR(dyn, obj, 60, alphas=alphas)
+    X, U, J, hist = sol.solve(torch.tensor(x1, device=device), torch.tensor(U0, device=device), **opts)
+    info = sol._dev.info()
+    fl, viol, rho = sol._dev.status()
+    assert info.al_done == 1 and (fl == 3).all(), (info.al_done, fl.cpu().numpy()[:8])
+    assert viol.max().item() < 0.005 and abs(obj.violation(X, U).max().item() - viol.max().item()) < 1e-12
+    assert (X[2] >= 1.0 - 0.005).all()                                          # stage constraint
+    assert (X[0, -1].abs() <= 0.5 + 0.005).all() and (X[1, -1].abs() <= 0.75 + 0.005).all()
+    assert (X[2:, -1] - torch.tensor(xT[2:], device=device)[:, None]).abs().max().item() < 0.005
+    UP = dyn.info.project(U.reshape(3, -1), grads=False)[0].double()
+    assert (torch.hypot(UP[0], UP[1]) <= UP[2] + 1e-2).all() and (UP[2] <= 12.5 + 1e-3).all()
+    print("rocket example with its constraints, %d problem(s), %s: %d iterations, %d multiplier updates, violation %.2e, objective %.1f .. %.1f"
+          % (B, str(dtype).split(".")[-1], info.iterations, info.al_iterations, viol.max().item(), obj.value(X, U).min().item(), obj.value(X, U).max().item()))
+    return info
+
+
+def check_batch_independence(lib, device, problem="cartpole", B=6, T=25, dtype=torch.float64, max_iter=10, max_al_iter=4, pick=(0, 3)):
+    """the B problems of a solver are independent solves that share their launches: every trajectory has its own regularisation
+    schedule, penalty and flags (csrc/od_ilqr_solver.inc::IlTraj), so what a problem converges to -- trajectory, controls, cost,
+    flags, violation -- does not depend on what else is in the batch: solved alone it gives the same numbers, bit for bit (the
+    kernels of a batch of one and of a batch of B are the same arithmetic; the iteration counts differ, the batch runs as long as
+    its slowest member)"""
+    im, obj, x1, U0 = constrained_problem(lib, device, problem, B, T, dtype=dtype)
+    x1t, Ut = torch.tensor(x1, device=device), torch.tensor(U0, device=device)
+    kw = dict(max_iter=max_iter, max_al_iter=max_al_iter, obj_tol=1e-7, con_tol=1e-4)
+    sol = IL.ILQR(im, obj, T)
+    X, U, J, hist = sol.solve(x1t, Ut, **kw)
+    fl, viol, rho = sol._dev.status()
+    for b in pick:
+        one = IL.ILQR(im, obj, T)
+        X1, U1, J1, h1 = one.solve(x1t[:, b:b + 1].contiguous(), Ut[:, :, b:b + 1].contiguous(), **kw)
+        f1, v1, r1 = one._dev.status()
+        assert torch.equal(X1[:, :, 0], X[:, :, b]) and torch.equal(U1[:, :, 0], U[:, :, b]) and torch.equal(J1[0], J[b]), (problem, b)
+        assert f1[0] == fl[b] and torch.equal(v1[0], viol[b]) and torch.equal(r1[0], rho[b]), (problem, b)
+    return fl, viol
+
+
 def check_device_iteration(lib, device, problem="cartpole", B=6, T=15, dtype=torch.float64, max_iter=8, max_al_iter=2, seed=1, tol=1e-9):
     """od_ilqr_* (the whole iteration on the device, decisions included) against the same loop composed from the separate entry
     points with the decisions on the host (ILQR.solve_stepwise): the same costs iteration by iteration, the same number of

@@ -72,6 +72,32 @@ def test_device_iteration_cpu(emu_lib):
     C.check_device_iteration(emu_lib, "cpu", "rocket", B=3, T=10, max_iter=5, max_al_iter=1, dtype=torch.float32)
 
 
+def test_device_iteration_constrained_cpu(emu_lib):
+    """stage and terminal affine constraints, inequalities by active set (od_ilqr_set_constraints)"""
+    C.check_device_iteration_constrained(emu_lib, "cpu", "cartpole")
+    C.check_device_iteration_constrained(emu_lib, "cpu", "rocket", B=3, T=10, max_iter=4, max_al_iter=3, expect_feasible=False)   # (0.5 s: cannot reach the goal)
+
+
+def test_batch_independence_cpu(emu_lib):
+    C.check_batch_independence(emu_lib, "cpu", "cartpole")
+    C.check_batch_independence(emu_lib, "cpu", "rocket", B=3, T=10, max_iter=4, max_al_iter=3, pick=(1,))
+
+
+@pytest.mark.gpu
+def test_batch_independence_gpu(gpu_lib):
+    import torch
+    C.check_batch_independence(gpu_lib, "cuda:0", "cartpole", B=40, pick=(0, 17, 39))
+    C.check_batch_independence(gpu_lib, "cuda:0", "rocket", B=70, T=30, max_iter=5, max_al_iter=3, pick=(0, 69), dtype=torch.float32)
+
+
+@pytest.mark.gpu
+def test_device_iteration_constrained_gpu(gpu_lib):
+    import torch
+    C.check_device_iteration_constrained(gpu_lib, "cuda:0", "cartpole", B=64, T=25, max_iter=15, max_al_iter=8)
+    C.check_device_iteration_constrained(gpu_lib, "cuda:0", "rocket", B=128, T=30, max_iter=5, max_al_iter=3, expect_feasible=False)
+    C.check_device_iteration_constrained(gpu_lib, "cuda:0", "rocket", B=128, T=30, max_iter=5, max_al_iter=3, dtype=torch.float32, expect_feasible=False)
+
+
 @pytest.mark.gpu
 def test_device_iteration_gpu(gpu_lib):
     import torch
@@ -108,3 +134,15 @@ def test_config5_rocket_projection_ilqr_as_stated(oracle, gpu_lib):
     """BASELINE config 5 at its size: T = 61, u_max = 12.5, the example's x1 / objective / initial controls, 1024 problems x 11 step
     sizes, double and single precision"""
     C.check_config5(oracle, gpu_lib, "cuda:0", B=1024, iters=12)
+
+
+def test_rocket_example_with_its_constraints_cpu(emu_lib):
+    """examples/rocket.jl `:projection` in full (stage inequality, terminal box and equalities) through od_ilqr_solve, one problem"""
+    C.check_rocket_example(emu_lib, "cpu", B=1)
+
+
+@pytest.mark.gpu
+def test_rocket_example_with_its_constraints_gpu(gpu_lib):
+    import torch
+    C.check_rocket_example(gpu_lib, "cuda:0", B=64)
+    C.check_rocket_example(gpu_lib, "cuda:0", B=64, dtype=torch.float32)
