@@ -20,7 +20,7 @@ export ImplicitDynamics, f, fx, fu, state_to_configuration, GradientBundle, fx_g
        RocketInfo, f_rocket, fx_rocket, fu_rocket, f_rocket_proj, fx_rocket_proj, fu_rocket_proj,
        soc_projection, soc_projection_gradient, ffxfu!,
        od_step_grad!, od_rollout!, od_rollout_compact!, od_rocket!, od_soc_project!, od_step_full!, model_indices,
-       ILQRSolver, initialize!, iterate!, al_update!, solve!, get_trajectory!
+       ILQRSolver, set_constraints!, get_status!, initialize!, iterate!, al_update!, solve!, get_trajectory!
 
 const LIB = get(ENV, "OD_MI355X_LIB", joinpath(@__DIR__, "..", "optimization_dynamics_amd", "libod_mi355x.so"))
 
@@ -338,6 +338,21 @@ function ILQRSolver(dyn, B::Integer, T::Integer; alphas=[2.0^-i for i in 0:10], 
     finalizer(x -> ccall((:od_ilqr_destroy, LIB), Cint, (Ptr{Cvoid},), x.s), s)
     return s
 end
+
+"""
+    set_constraints!(s; Cs, Ds, ds, n_stage_ineq, Ct, dt, n_terminal_ineq)
+
+Affine constraints by augmented Lagrangian (iLQR.Constraint with idx_ineq, examples/rocket.jl:82-110): stage rows
+`Cs x_t + Ds u_t - ds` (t < T) and terminal rows `Ct x_T - dt`; the first `n_*_ineq` rows of each are inequalities (<= 0).
+"""
+function set_constraints!(s::ILQRSolver; Cs=zeros(0, 0), Ds=zeros(0, 0), ds=Float64[], n_stage_ineq=0, Ct=zeros(0, 0), dt=Float64[], n_terminal_ineq=0)
+    check(ccall((:od_ilqr_set_constraints, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}),
+                s.s, length(ds), n_stage_ineq, Matrix{Float64}(Cs), Matrix{Float64}(Ds), Float64.(collect(ds)),
+                length(dt), n_terminal_ineq, Matrix{Float64}(Ct), Float64.(collect(dt))))
+end
+"per problem: flags (bit 0 inner loop converged, bit 1 constraints met), violation, penalty -- device arrays of length B"
+get_status!(s::ILQRSolver, flags, violation, penalty) =
+    check(ccall((:od_ilqr_get_status, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), s.s, pointer(flags), pointer(violation), pointer(penalty)))
 
 "initialize_controls! + rollout + first linearisation (examples/acrobot.jl:108-113); x1, U0 device arrays"
 initialize!(s::ILQRSolver, x1, U0) = check(ccall((:od_ilqr_init, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), s.s, pointer(x1), pointer(U0)))

@@ -93,7 +93,9 @@ def test_batch_independence_gpu(gpu_lib):
 @pytest.mark.gpu
 def test_device_iteration_constrained_gpu(gpu_lib):
     import torch
-    C.check_device_iteration_constrained(gpu_lib, "cuda:0", "cartpole", B=64, T=25, max_iter=15, max_al_iter=8)
+    # (eight multiplier rounds: the penalty reaches 1e8 and with it the sensitivity of the iteration to the last bits of the costs,
+    # which the cost kernels and torch round differently on the device -- 1e-6 here, 1e-9 / bit for bit on the host build)
+    C.check_device_iteration_constrained(gpu_lib, "cuda:0", "cartpole", B=64, T=25, max_iter=15, max_al_iter=8, tol=1e-6)
     C.check_device_iteration_constrained(gpu_lib, "cuda:0", "rocket", B=128, T=30, max_iter=5, max_al_iter=3, expect_feasible=False)
     C.check_device_iteration_constrained(gpu_lib, "cuda:0", "rocket", B=128, T=30, max_iter=5, max_al_iter=3, dtype=torch.float32, expect_feasible=False)
 
