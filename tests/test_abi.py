@@ -131,11 +131,12 @@ def _null_fuzz(emu_lib, device):
         s = C.c_void_p()
         assert cd.od_ilqr_create(h, 4, 3, 2, al, None, C.byref(s)) == 0, cd.od_last_error()
         for name in ("od_ilqr_init", "od_ilqr_iterate", "od_ilqr_al_update", "od_ilqr_solve", "od_ilqr_get", "od_ilqr_get_history",
-                     "od_ilqr_set_objective"):
+                     "od_ilqr_set_objective", "od_ilqr_get_status"):
             fn = getattr(cd, name)
             r = fn(*_zero_args(fn, s))
             assert isinstance(r, int) and (r < 0 or (r == 0 and name == "od_ilqr_get_history")), (model, name, r)   # (no rows asked for: none)
         assert cd.od_ilqr_get_info(s, None) < 0
+        assert cd.od_ilqr_set_constraints(s, 17, 0, None, None, None, 0, 0, None, None) < 0 and cd.od_ilqr_set_constraints(s, 2, 0, None, None, None, 0, 0, None, None) < 0
         assert cd.od_ilqr_destroy(s) == 0
 
 
