@@ -446,6 +446,81 @@ def check_rocket_example(lib, device, B=1, dtype=torch.float64):
     return info
 
 
+def planar_push_example(lib, device, mode, B, seed=1):
+    """examples/planar_push.jl (`:rotate` / `:translate`): h = 0.1, T = 26, kappa_eval 1e-4, kappa_grad 1e-2 (:18-22); objective
+    1/2 v1'W v1 + 1/2 (x - xT)'Wx (x - xT) + 1/2 ru u'u per stage, without the control term at the horizon (:57-83) -- a quadratic
+    form in x: 1/2 (x - x*)'Q(x - x*) + const with Q = Qv + Wx, x* = Q^-1 Wx xT; control limits -5 <= u <= 5 as stage inequalities
+    (:90-99), goal on rows 1:3, 6:8 as terminal equalities (:101-104); initial controls of :111; options of :117-128.  Problem b > 0
+    perturbs the initial controls by 1e-2 randn."""
+    import math
+    h, T, r_dim = 0.1, 25, 0.1
+    im = P.make_im("planar_push", lib, device)
+    if mode == "translate":
+        q0 = [0.0, 0.0, 0.0, -r_dim - 1.0e-8, 0.0]; goal = (1.0, 0.0, 0.0); ru = 1.0e-1
+        U0 = np.zeros((2, T)); U0[0, :4] = 1.0
+    else:
+        q0 = [0.0, 0.0, 0.0, -r_dim - 1.0e-8, -0.01]; goal = (0.5, 0.5, 0.5 * math.pi); ru = 1.0e-2
+        U0 = np.zeros((2, T)); U0[0, :4] = 1.0; U0[0, 4:9] = 0.5
+    qT = [goal[0], goal[1], goal[2], goal[0] - r_dim, goal[1] - r_dim]
+    xT = np.array(qT + qT)
+    W = np.diag([1.0, 1.0, 1.0, 0.1, 0.1]); Wx = np.diag([1.0, 1.0, 1.0, 0.1, 0.1] * 2)
+    Qv = np.block([[W, -W], [-W, W]]) / h ** 2
+    Q = Qv + Wx
+    xs = np.linalg.solve(Q, Wx @ xT)
+    obj = IL.QuadraticObjective(Q, ru * np.eye(2), Q, x_ref=xs, goal_idx=[0, 1, 2, 5, 6, 7], goal=xT[[0, 1, 2, 5, 6, 7]], device=device)
+    Cs = np.zeros((4, 10)); Ds = np.vstack([-np.eye(2), np.eye(2)]); ds = np.array([5.0, 5.0, 5.0, 5.0])
+    obj.set_constraints(stage=(Cs, Ds, ds, 4))
+    rng = np.random.default_rng(seed)
+    U = np.repeat(U0[:, :, None], B, axis=2)
+    U[:, :, 1:] += 1e-2 * rng.normal(size=(2, T, B - 1))
+    x1 = np.repeat(np.array(q0 + q0)[:, None], B, axis=1)
+    opts = dict(max_iter=10, max_al_iter=10, con_tol=0.005, obj_tol=1.0e-3)
+    return im, obj, x1, U, xT, T, opts
+
+
+def cartpole_example(lib, device, mode, B, seed=1):
+    """examples/cartpole.jl: swing-up, h = 0.05, T = 51, objective u'u per stage and (x - xT)'(x - xT) at the horizon (:50-60), terminal
+    constraint x = xT = [0, pi, 0, pi] (:66-70), initial controls -1.5 at the first knot (:77), options of :83-94; `:frictionless` (the
+    file's default: kappa 1.0) or `:friction` (joint friction 0.35, kappa_eval 1e-4 / kappa_grad 1e-3)"""
+    import math
+    T = 50
+    name = "cartpole_friction" if mode == "friction" else "cartpole_frictionless"
+    im = P.make_im(name, lib, device)
+    if mode != "friction":
+        im.set_options(kappa_eval_tol=1.0, kappa_grad_tol=1.0)
+    xT = np.array([0.0, math.pi, 0.0, math.pi])
+    obj = IL.QuadraticObjective(np.zeros((4, 4)), 2.0 * np.eye(1), 2.0 * np.eye(4), x_ref=xT, goal_idx=[0, 1, 2, 3], goal=xT, device=device)
+    U0 = np.zeros((1, T, B)); U0[0, 0] = -1.5
+    U0[:, :, 1:] += 1e-2 * np.random.default_rng(seed).normal(size=(1, T, B - 1))
+    opts = dict(max_iter=100, max_al_iter=20, con_tol=0.005, obj_tol=1.0e-5)
+    return im, obj, np.zeros((4, B)), U0, xT, T, opts
+
+
+def check_reference_example(lib, device, which, B=1, need=1.0):
+    """one of the reference's examples through od_ilqr_solve (the whole solve on the device): constraints to the example's con_tol
+    on at least `need` of the problems, controls inside their limits, the returned trajectory consistent with its controls"""
+    if which.startswith("planar_push"):
+        im, obj, x1, U0, xT, T, opts = planar_push_example(lib, device, which.split(":")[1], B)
+    else:
+        im, obj, x1, U0, xT, T, opts = cartpole_example(lib, device, which.split(":")[1], B)
+    sol = IL.ILQR(im, obj, T, alphas=tuple(2.0 ** -i for i in range(17)))
+    x1t, Ut = torch.tensor(x1, device=device), torch.tensor(U0, device=device)
+    X, U, J, hist = sol.solve(x1t, Ut, **opts)
+    info = sol._dev.info()
+    fl, viol, rho = sol._dev.status()
+    okc = (viol < opts["con_tol"])
+    assert okc.double().mean().item() >= need, (which, okc.double().mean().item(), viol.max().item())
+    assert ((fl & 2) != 0).eq(okc).all()
+    if obj.stage is not None:
+        assert (U.abs() <= 5.0 + opts["con_tol"]).all()
+    Xr = im.rollout(x1t, U, grads=False)[0]
+    assert (Xr - X).abs().max().item() < 1e-9
+    print("%s, %d problem(s): %d lockstep iterations, %d multiplier rounds, %.0f %% at con_tol, max violation %.2e, goal error %.2e"
+          % (which, B, info.iterations, info.al_iterations, 100 * okc.double().mean().item(), viol.max().item(),
+             (X[:, -1] - torch.tensor(xT, device=device)[:, None])[obj.goal_idx.cpu()].abs().max().item()))
+    return info, viol
+
+
 def check_batch_independence(lib, device, problem="cartpole", B=6, T=25, dtype=torch.float64, max_iter=10, max_al_iter=4, pick=(0, 3)):
     """the B problems of a solver are independent solves that share their launches: every trajectory has its own regularisation
     schedule, penalty and flags (csrc/od_ilqr_solver.inc::IlTraj), so what a problem converges to -- trajectory, controls, cost,

@@ -148,3 +148,15 @@ def test_rocket_example_with_its_constraints_gpu(gpu_lib):
     import torch
     C.check_rocket_example(gpu_lib, "cuda:0", B=64)
     C.check_rocket_example(gpu_lib, "cuda:0", B=64, dtype=torch.float32)
+
+
+def test_reference_examples_on_the_device_cpu(emu_lib):
+    """examples/cartpole.jl (frictionless, the file's default) and examples/planar_push.jl `:translate` through od_ilqr_solve, one problem each (host build)"""
+    C.check_reference_example(emu_lib, "cpu", "cartpole:frictionless")
+    C.check_reference_example(emu_lib, "cpu", "planar_push:translate")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["cartpole:frictionless", "planar_push:rotate", "planar_push:translate"])
+def test_reference_examples_on_the_device_gpu(gpu_lib, which):
+    C.check_reference_example(gpu_lib, "cuda:0", which, B=32, need=0.9)
