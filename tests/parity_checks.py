@@ -8,8 +8,11 @@ dz = -rz^{-1} rtheta solved in IEEE binary128 at a given iterate) on 100 % of th
   * device against oracle: <= 1e-4 + what the exact gradients at the two iterates differ by.
 At converged contact modes rz has condition numbers up to 1e27 and the two implementations' iterates differ by
 ~1e-11 (both inside r_tol): the exact gradient itself then moves by up to 1e-2 between the two iterates -- measured,
-profiles/r2_parity_sweep.json -- while each solver reproduces its own exact gradient to 1e-12.  Where no iterate is
-available (rollout knots, callbacks) assert_grad_close keeps the statistical form (1e-4 on >= 99.8 %, 1e-9 median)."""
+profiles/r2_parity_sweep.json -- while each solver reproduces its own exact gradient to 1e-12.
+Round 4: the statistical form (assert_grad_close: 1e-4 on >= 99.8 %, 1e-9 median) is left at ONE site, the finite-undercut
+rollout against the oracle, where the two simulators of the reference iterate separately and no single iterate is recorded;
+comparisons between two device paths are bit for bit where they share the gradient pass, and held to the arbiter with the
+knot's own condition number (assert_grad_conditioned) where two compilations of the same arithmetic meet."""
 import numpy as np
 import torch
 
@@ -221,10 +224,8 @@ def check_rollout(oracle, lib, device, B, T, name="hopper", u_sigma=0.3):
     # the compiler's instruction scheduling / FMA contraction of the two kernels
     # the split rollout differentiates in the SAME second-pass kernel on the same recorded iterates: bit for bit
     assert torch.equal(A[:, :, t], DX) and torch.equal(Bm[:, :, t], DU), "rollout vs step_grad"
-    # gradients along the trajectory vs the oracle on the oracle's states (first knots)
-    G = np.concatenate([An[:, :, 0], Bn[:, :, 0]], 1)
-    Go = np.concatenate([Ao[:, :, 0], Bo[:, :, 0]], 1)
-    assert_grad_close(G, Go, ok, "rollout knot 0")
+    # (gradients: every knot is held to the binary128 arbiter below -- the statistical comparison of knot 0 with the oracle's that
+    # stood here is subsumed by it)
     # EVERY knot of the rollout through the binary128 arbiter, at the iterate the rollout's gradient pass differentiated at
     # (the hand-over workspace holds all T*B of them, knot k = t*B + b): the device's states are the inputs
     n, nu = Xn.shape[0], U.shape[0]
@@ -836,9 +837,14 @@ def check_rollout_instantiation(oracle, lib, device, B, T, B_ref, n_oracle=256, 
     scale = np.maximum(1e-2, np.abs(Xo)[:, :, ok].max(0))
     assert (err / scale)[: min(T, 10) + 1].max() < STATE_TOL, (err / scale)[: min(T, 10) + 1].max()
     assert np.median((err / scale)[-1]) < 1e-6
+    # knot 0 of those trajectories through the binary128 arbiter, at the iterates the rollout's gradient pass recorded (knot
+    # k = t*B + b: the first B entries of the hand-over workspace) -- device vs exact <= 1e-8, device vs oracle <= 1e-4 + what the
+    # two iterates explain, on every converged knot
+    im.rollout_compact(x1d, Ud)
+    Zd = im.grad_iterates(T * B)[:, :n].cpu().numpy()
     Gn = G[:, :, 0, :n].cpu().numpy()
-    Go = np.concatenate([Ao[4:, :, 0], Bo[4:, :, 0]], 1)
-    assert_grad_close(Gn, Go, ok, "knot 0 vs oracle")
+    ok0 = conv[0, :n].cpu().numpy()
+    assert_grad_exact(oracle, im, "hopper", np.ascontiguousarray(x1[:, :n]), np.ascontiguousarray(U[:, 0, :n]), None, None, ok0, "rollout knot 0", Gd=Gn, Zd=Zd)
     return im
 
 

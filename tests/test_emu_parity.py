@@ -259,7 +259,6 @@ def test_lane_cooperation_in_lockstep_rows(emu_lib, name):
             cur = im.step_grad(torch.tensor(X), torch.tensor(U))
             assert torch.equal(ref[3], cur[3]) and torch.equal(ref[4], cur[4]), ppw
             assert torch.equal(ref[0], cur[0]), ppw
-            ok = ((cur[3] & 3) == 3).numpy()
-            P.assert_grad_close(np.concatenate([ref[1].numpy(), ref[2].numpy()], 1), np.concatenate([cur[1].numpy(), cur[2].numpy()], 1), ok, "ppw %d" % ppw)
+            assert torch.equal(ref[1], cur[1]) and torch.equal(ref[2], cur[2]), ppw      # (same iterates, the same gradient pass)
     finally:
         emu_lib.cdll.od_emu_set_lockstep(0)
