@@ -366,23 +366,24 @@ def main():
         aux = dict(workload="od_step_grad, hopper, %d independent knots" % Bk, units_per_s=Bk / tk, ms=tk * 1e3,
                    mean_iterations=float(itk[0].double().mean().item()))
 
-    aux_roll = None
+    aux_roll = aux_c4 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not emu:
-        # auxiliary, NOT the headline: the same rollout step at a batch that fills the chip (65 536 trajectories x T knots, 64
-        # per wavefront) -- where the roofline fraction of this path stands when the batch is not the limit
-        Br = 65536
-        xr, Ur = workload_slice(0, Br, Br, T)
-        xrd, Urd = torch.tensor(xr, device=dev), torch.tensor(Ur, device=dev)
-        orr = None
-        orr = im.rollout_compact(xrd, Urd, out=orr)[-1]
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ts = []
-        for _ in range(3):
-            e0.record(stream); r_ = im.rollout_compact(xrd, Urd, out=orr); orr = r_[-1]; e1.record(stream); sync()
-            ts.append(e0.elapsed_time(e1))
-        aux_roll = dict(workload="od_rollout_compact, hopper, %d rollouts x T=%d" % (Br, T), ms=float(np.median(ts)), units_per_s=Br * T / (np.median(ts) * 1e-3),
+        # auxiliary, NOT the headline: the same rollout step at BASELINE.json's configs[3] (8192 rollouts: 8 lanes per problem) and
+        # at a batch that fills the chip (65 536 trajectories x T knots, 64 per wavefront) -- where the roofline fraction of this
+        # path stands when the batch is not the limit
+        def large(Br):
+            xr, Ur = workload_slice(0, Br, Br, T)
+            xrd, Urd = torch.tensor(xr, device=dev), torch.tensor(Ur, device=dev)
+            orr = im.rollout_compact(xrd, Urd, out=None)[-1]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ts = []
+            for _ in range(3):
+                e0.record(stream); r_ = im.rollout_compact(xrd, Urd, out=orr); orr = r_[-1]; e1.record(stream); sync()
+                ts.append(e0.elapsed_time(e1))
+            return dict(workload="od_rollout_compact, hopper, %d rollouts x T=%d" % (Br, T), ms=float(np.median(ts)), units_per_s=Br * T / (np.median(ts) * 1e-3),
                         mean_iterations=float(r_[3][0].double().mean().item()))
-        del orr, r_, xrd, Urd
+        aux_c4 = large(8192)
+        aux_roll = large(65536)
 
     if rank == 0:
         stats = json.load(open(os.path.join(ROOT, "optimization_dynamics_amd", "csrc", "gen", "stats.json")))["hopper"]
@@ -429,11 +430,12 @@ def main():
         }
         if strong is not None:
             line["strong_scaling"] = strong
-        if aux_roll is not None:
-            Fr_, _, _ = algorithmic_flops_per_unit(aux_roll["mean_iterations"], stats)
-            aux_roll["algorithmic_tflops"] = Fr_ * aux_roll["units_per_s"] / 1e12
-            aux_roll["algorithmic_frac"] = aux_roll["algorithmic_tflops"] / FP64_PEAK_TFLOPS
-            line["aux_large_batch_rollouts"] = aux_roll
+        for key_, blk in (("aux_config_4", aux_c4), ("aux_large_batch_rollouts", aux_roll)):
+            if blk is not None:
+                Fr_, _, _ = algorithmic_flops_per_unit(blk["mean_iterations"], stats)
+                blk["algorithmic_tflops"] = Fr_ * blk["units_per_s"] / 1e12
+                blk["algorithmic_frac"] = blk["algorithmic_tflops"] / FP64_PEAK_TFLOPS
+                line[key_] = blk
         if aux is not None:
             Fk, _, _ = algorithmic_flops_per_unit(aux["mean_iterations"], stats)
             aux["algorithmic_tflops"] = Fk * aux["units_per_s"] / 1e12

@@ -46,6 +46,43 @@ def _worker(rank, world, port, emu_path, outdir):
     dist.destroy_process_group()
 
 
+def _ilqr_worker(rank, world, port, emu_path, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ilqr_checks as C
+    from optimization_dynamics_amd import _lib, ilqr as IL, parallel
+    lib = _lib.Library(emu_path)
+    B, T = 6, 25
+    im, obj, x1, U0 = C.constrained_problem(lib, "cpu", "cartpole", B, T)
+    lo, hi = parallel.shard_range(B, world, rank)
+    X, U, J, hist = IL.ILQR(im, obj, T).solve(torch.tensor(x1[:, lo:hi]), torch.tensor(U0[:, :, lo:hi]), max_iter=10, max_al_iter=4,
+                                              obj_tol=1e-7, con_tol=1e-4)
+    (Xg, Ug, Jg), _ = parallel.gather_batch([X.contiguous(), U.contiguous(), J.contiguous()])
+    if rank == 0:
+        cat = lambda t: torch.cat(list(t.unbind(0)), dim=-1).numpy()
+        np.savez(os.path.join(outdir, "ilqr.npz"), X=cat(Xg), U=cat(Ug), J=cat(Jg))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_ilqr_solves(emu_lib, tmp_path):
+    """the iLQR iteration shards like the path itself: the problems of a solver are independent solves (per-trajectory solver
+    state), so two ranks each solving half of the batch with od_ilqr_solve -- no collective inside the solve -- and gathering the
+    results give the unsharded solve's trajectories, controls and costs bit for bit"""
+    world = 2
+    mp.spawn(_ilqr_worker, args=(world, _free_port(), emu_lib.path, str(tmp_path)), nprocs=world, join=True)
+    g = np.load(tmp_path / "ilqr.npz")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ilqr_checks as C
+    from optimization_dynamics_amd import ilqr as IL
+    im, obj, x1, U0 = C.constrained_problem(emu_lib, "cpu", "cartpole", 6, 25)
+    X, U, J, hist = IL.ILQR(im, obj, 25).solve(torch.tensor(x1), torch.tensor(U0), max_iter=10, max_al_iter=4, obj_tol=1e-7, con_tol=1e-4)
+    assert np.array_equal(g["X"], X.numpy()) and np.array_equal(g["U"], U.numpy()) and np.array_equal(g["J"], J.numpy())
+
+
 def test_shard_range_partitions():
     from optimization_dynamics_amd.parallel import shard_range
     for n in (1, 7, 8, 4096, 8192):
