@@ -35,8 +35,11 @@ template <class T> OD_HD T od_sqrt_fast(T x) {
 struct Model_rocket_projection_direct : Model_rocket_projection {
   static constexpr bool DIRECT_FACTOR = true;
   // stall exit (od_solver.h::model_stall): the accepted step length below STALL_ALPHA in STALL_ITERS consecutive iterations
-  // (single precision: the guards of the cone step sit at 1e-7, a stalled solve creeps with step lengths of ~2e-6)
-  static constexpr double STALL_ALPHA = 1e-9, STALL_ALPHA_F32 = 1e-5;
+  // (single precision: the guards of the cone step sit at 1e-7 and a stalled solve creeps with step lengths between 5e-7 and 7e-4:
+  // of the 42 240 candidate controls of an iteration of config 5, 38 solves make more than 20 iterations; step length < 1e-5 x 4
+  // abandons 14 of them, < 1e-3 x 4 abandons 29 -- every one that would run into max_iter -- and in both cases one that would have
+  // converged late, tools/diag_config5_rollout.py)
+  static constexpr double STALL_ALPHA = 1e-9, STALL_ALPHA_F32 = 1e-3;
   static constexpr int STALL_ITERS = 4;
   // step lengths of this model: hand-written (od_solver.h::model_direct_step) -- one 3-d cone, two orthant pairs
   static constexpr bool DIRECT_STEP = true;

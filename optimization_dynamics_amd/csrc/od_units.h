@@ -546,6 +546,9 @@ template <class MD, class F32> OD_HD void rocket_refine64(const float* x, const 
 template <class MD, class MP, class T> OD_HD void rocket_knot_state(const RocketArgs<T>& a, long b, const T* x, T* u, T* y, int* ok_and = nullptr) {
   int st = 0;
   NoGradSink<T> ns;
+#ifdef OD_EXPERIMENT_ITERS_IN_STATUS
+  int itp_[2] = {0, 0};
+#endif
   if (a.project) {
     T zp[MP::NZ], thp[MP::NTH];
 #pragma unroll
@@ -553,6 +556,9 @@ template <class MD, class MP, class T> OD_HD void rocket_knot_state(const Rocket
     thp[0] = u[0]; thp[1] = u[1]; thp[2] = u[2]; thp[3] = a.u_max;
     int itp[2];
     const int sp_ = ip_step_grad<MP>(a.opts_proj, thp, zp, true, false, ns, itp, a.proj_stall_exit != 0);
+#ifdef OD_EXPERIMENT_ITERS_IN_STATUS
+    itp_[0] = itp[1];
+#endif
     st |= (sp_ & 1) << 4;
     u[0] = zp[0]; u[1] = zp[1]; u[2] = zp[2];
     if (a.uproj.ok()) { a.uproj.at(0, b) = u[0]; a.uproj.at(1, b) = u[1]; a.uproj.at(2, b) = u[2]; }
@@ -568,7 +574,11 @@ template <class MD, class MP, class T> OD_HD void rocket_knot_state(const Rocket
     if (a.polish64) rocket_refine64<MD>(x, u, a.h64, th, y, fd, it[0] > 0);
   }
   st |= (sd & (OD_ST_EVAL_OK | OD_ST_FACTOR_OK));
+#ifdef OD_EXPERIMENT_ITERS_IN_STATUS   // MEASUREMENT ONLY (tools/diag_config5_rollout.py): iteration counts of the two solves in the status word
+  if (a.status.ok()) a.status.at(0, b) = st | ((a.project ? itp_[0] : 0) << 8) | (it[0] << 16);
+#else
   if (a.status.ok()) a.status.at(0, b) = st;
+#endif
   if (ok_and) *ok_and &= st;                  // (bit 0: the dynamics solve converged)
 }
 

@@ -483,7 +483,7 @@ def check_soc_projection(oracle, lib, device, B=96):
 
 def check_projection_stall_exit(lib, device, B=40000):
     """od_set_projection_stall_exit (csrc/od_solver.h::model_stall, DESIGN.md 3.5): a projection that has stalled on the boundary
-    of the cone -- accepted step length < 1e-9 (float: 1e-5) for 4 consecutive iterations -- is abandoned as if it had run into
+    of the cone -- accepted step length < 1e-9 (float: 1e-3) for 4 consecutive iterations -- is abandoned as if it had run into
     max_iter.  (i) a solve the exit does not abandon is untouched: wherever the run WITH the exit reports convergence, result and
     status are bit for bit those of the run without; (ii) an abandoned solve is reported as not converged; where the full loop
     stays stalled to max_iter (most of them) its iterate is the abandoned one to 1e-8, the rest leave the stall by rounding drift
@@ -509,8 +509,19 @@ def check_projection_stall_exit(lib, device, B=40000):
         near = 0
         if both_bad.any():                                                                                                                      # (ii)
             d = (UP1[:, both_bad] - UP0[:, both_bad]).abs().max(0).values
-            near = int((d < (1e-8 if dtype == torch.float64 else 1e-3)).sum().item())
-            assert near >= both_bad.sum().item() // 2, (near, int(both_bad.sum().item()))
+            if dtype == torch.float64:
+                near = int((d < 1e-8).sum().item())
+            else:
+                # single precision: a stalled solve creeps with step lengths up to ~7e-4 (the guards of the cone step sit at 1e-7), so
+                # the full loop's last iterate is a few 1e-3 further along the same creep -- and no nearer the solution: both are
+                # held against the closed-form projection (oracle.project_thrust_cone)
+                from oracle import oracle as O
+                jj = both_bad.nonzero().reshape(-1).tolist()
+                ex = np.stack([O.project_thrust_cone(U[:, j], 12.5) for j in jj], axis=1)
+                e1 = np.abs(UP1[:, both_bad].double().cpu().numpy() - ex).max(0)
+                e0 = np.abs(UP0[:, both_bad].double().cpu().numpy() - ex).max(0)
+                near = int((e1 <= 2.0 * e0 + 1e-3).sum())
+            assert near >= (both_bad.sum().item() // 2 if dtype == torch.float64 else 0.8 * both_bad.sum().item()), (near, int(both_bad.sum().item()))
         lucky = int((~ok1 & ok0).sum().item())
         n_stall = int((~ok1).sum().item())
         assert lucky <= max(3, B // 1000), lucky                                                                                               # (iii)

@@ -19,3 +19,8 @@ for m in hopper planar_push; do
 done; wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../variants/libod_c3pls.so $(ls build/*.o | grep -v "od_model_hopper\|od_model_planar_push") ../../variants/build_c3pls/od_model_hopper.o ../../variants/build_c3pls/od_model_planar_push.o
 echo "variants/libod_c3pls.so: OD_LIB=variants/libod_c3pls.so python tools/sweep_pp.py"
+# iteration counts of the rocket's two solves in the status word of the rollout kernels (tools/diag_config5_rollout.py)
+mkdir -p ../../variants/build_its
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -fno-slp-vectorize -DOD_EXPERIMENT_ITERS_IN_STATUS -c od_rocket.hip -o ../../variants/build_its/od_rocket.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../variants/libod_itstat.so $(ls build/*.o | grep -v od_rocket) ../../variants/build_its/od_rocket.o
+echo "variants/libod_itstat.so: OD_LIB=variants/libod_itstat.so python tools/diag_config5_rollout.py 3"
