@@ -28,8 +28,50 @@ def test_every_ccall_of_the_shim_names_an_exported_symbol_with_matching_arity(em
     for sym, ret, args in calls:
         assert hasattr(emu_lib.cdll, sym), sym
         if sym in _lib.SIGNATURES:
-            nargs = len([a for a in args.split(",") if a.strip()])
-            assert nargs == len(_lib.SIGNATURES[sym][1]), (sym, nargs, len(_lib.SIGNATURES[sym][1]))
+            jargs = [a.strip() for a in args.split(",") if a.strip()]
+            assert len(jargs) == len(_lib.SIGNATURES[sym][1]), (sym, len(jargs), len(_lib.SIGNATURES[sym][1]))
+            # ... and the same class of C type in every position (a Cint where the header says long reads garbage on x86-64)
+            import ctypes as C
+            def jclass(t):
+                return "ptr" if t.startswith(("Ptr", "Ref", "Cstring")) else {"Cint": "int", "Clong": "long", "Cdouble": "double"}[t]
+            def cclass(t):
+                return {C.c_int: "int", C.c_long: "long", C.c_double: "double"}.get(t, "ptr")
+            assert [jclass(a) for a in jargs] == [cclass(t) for t in _lib.SIGNATURES[sym][1]], sym
+            assert jclass(ret) == cclass(_lib.SIGNATURES[sym][0]), sym
+
+
+def _c_struct_fields(header, name):
+    """[(type, field)] of `typedef struct { ... } name;` in the header, in declaration order"""
+    end = re.search(r"\}\s*%s;" % name, header).start()
+    start = header.rindex("typedef struct {", 0, end) + len("typedef struct {")
+    body = re.sub(r"/\*.*?\*/", "", header[start:end], flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            ty, names = decl.split(None, 1)
+            out += [(ty, n.strip()) for n in names.split(",")]
+    return out
+
+
+def test_struct_mirrors_match_the_header_field_for_field():
+    """the structs the C ABI passes by pointer (od_options, od_ilqr_options, od_ilqr_info) are mirrored twice -- ctypes
+    (optimization_dynamics_amd/_lib.py) and Julia (julia/OptimizationDynamicsMI355X.jl) -- and nothing but this test holds the three
+    declarations together: same fields, same order, same C types"""
+    import ctypes as C
+    from optimization_dynamics_amd import _lib
+    header = open(os.path.join(ROOT, "include", "od_mi355x.h")).read()
+    jl = open(os.path.join(ROOT, "julia", "OptimizationDynamicsMI355X.jl")).read()
+    ctype = {"double": C.c_double, "int": C.c_int, "long": C.c_long}
+    jtype = {"double": "Cdouble", "int": "Cint", "long": "Clong"}
+    for cname, py, jname in (("od_options", _lib.Options, "ODOptions"), ("od_ilqr_options", _lib.IlqrOptions, "ILQROptions"),
+                             ("od_ilqr_info", _lib.IlqrInfo, "ILQRInfo")):
+        fields = _c_struct_fields(header, cname)
+        assert len(fields) >= 9
+        assert [(n, t) for n, t in py._fields_] == [(n, ctype[ty]) for ty, n in fields], cname
+        m = re.search(r"struct %s\b[^\n]*\n(.*?)\nend" % jname, jl, re.S)
+        jf = [tuple(f.strip().split("::")) for line in m.group(1).split("\n") for f in line.split("#")[0].split(";") if f.strip()]
+        assert jf == [(n, jtype[ty]) for ty, n in fields], (jname, jf)
 
 
 def test_implicit_dynamics_callbacks_sequence(oracle, emu_lib):
