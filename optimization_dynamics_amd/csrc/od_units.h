@@ -15,9 +15,16 @@ namespace od {
 // interior-point loop and are spilled to VGPR lanes (v_writelane/v_readlane)
 #define OD_OPAQUE_PTR(p) asm volatile("" : "+v"(p))
 #define OD_GLOBAL_PTR(T, p) ((T __attribute__((address_space(1)))*)(p))
+// small tables of constants the host wrote before the launch, read at a wavefront-uniform address inside a long loop: through the
+// constant address space (scalar loads, their own counter, the scalar cache) from a pointer the compiler cannot look through --
+// read where they are used instead of living in SGPRs (and, spilled, in VGPR lanes) across the loop
+#define OD_CONST_PTR(T, p) ((const T __attribute__((address_space(4)))*)(p))
+#define OD_OPAQUE_SPTR(p) asm volatile("" : "+s"(p))
 #else
 #define OD_OPAQUE_PTR(p) (void)0
 #define OD_GLOBAL_PTR(T, p) (p)
+#define OD_CONST_PTR(T, p) (p)
+#define OD_OPAQUE_SPTR(p) (void)0
 #endif
 
 template <class T> struct View {
@@ -699,7 +706,7 @@ template <class T> struct RocketRolloutArgs {
   // up along its rollout -- J_p = sum_t 1/2 (x_t - xref)'Q(x_t - xref) + 1/2 u_t'R u_t + 1/2 (x_T - xref)'QT(x_T - xref), in double,
   // knot after knot (a fixed order: the cost decides the Armijo comparison) -- instead of a second pass over the candidates'
   // states; okall[p] = every dynamics solve of the rollout converged.  All null otherwise.
-  const double *cq, *cr, *cqt, *cxref;   // diagonals of Q (12), R (3), QT (12); xref (12)
+  const double *cq, *cr, *cqt, *cxref;   // diagonals of Q (12), R (3) -- contiguous: cr = cq + 12 --, QT (12); xref (12)
   double* J;
   int* okall;
 };
@@ -717,45 +724,50 @@ template <class MD, class MP, class T> OD_HD void unit_rocket_rollout(const Rock
   }
   double Jacc = 0.0;
   int okk = 1;
-  // (the objective's constants once, before the recursion: a load inside it would wait behind the knot's stores -- the memory
-  // counter is in order)
-  double cq[12], cr[3], cx[12];
-  if (ra.J) {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) { cq[i] = ra.cq[i]; cx[i] = ra.cxref[i]; }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) cr[j] = ra.cr[j];
-  }
+  // Everything a knot reads and writes goes through running pointers (View::Cursor: one 64-bit add per element): indexing the views
+  // with (element, knot) leaves ~70 hoisted row offsets in SGPRs across the recursion, and with the 27 constants of the objective
+  // the kernel spilled 357 SGPRs to VGPR lanes -- ~1 500 of the ~5 300 instructions of a knot (tools/isa_attrib.py rocket).
   for (int t = 0; t < ra.Tn; ++t) {
     const long kn = (long)t * ra.Bnom + b, kc = (long)t * a.B + p;
+    {
+      auto c = ra.ubar.cursor(kn);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) u[j] = ra.ubar.at(j, kn);
+      for (int j = 0; j < 3; ++j) u[j] = c.get();
+    }
     if (ra.nalpha > 0) {
+      auto cf = ra.kff.cursor(kn);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) u[j] += alpha * ra.kff.at(j, kn);
+      for (int j = 0; j < 3; ++j) u[j] += alpha * cf.get();
+      auto cx_ = ra.xbar.cursor(kn);
+      auto ck = ra.K.cursor(kn);
 #pragma unroll
       for (int i = 0; i < 12; ++i) {
-        const T dxi = x[i] - ra.xbar.at(i, kn);
+        const T dxi = x[i] - cx_.get();
 #pragma unroll
-        for (int j = 0; j < 3; ++j) u[j] += ra.K.at(j + 3 * i, kn) * dxi;
+        for (int j = 0; j < 3; ++j) u[j] += ck.get() * dxi;          // (element j + 3 i)
       }
     }
     if (ra.U.ok()) {
+      auto c = ra.U.cursor(kc);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) ra.U.at(j, kc) = u[j];
+      for (int j = 0; j < 3; ++j) c.put(u[j]);
     }
     if (ra.J) {
+      auto cq = OD_CONST_PTR(double, ra.cq);       // diag Q (12), diag R (3) behind it
+      auto cx = OD_CONST_PTR(double, ra.cxref);
+      OD_OPAQUE_SPTR(cq); OD_OPAQUE_SPTR(cx);
       double s = 0.0;
 #pragma unroll
       for (int i = 0; i < 12; ++i) { const double v = (double)x[i] - cx[i]; s += cq[i] * v * v; }
 #pragma unroll
-      for (int j = 0; j < 3; ++j) { const double v = (double)u[j]; s += cr[j] * v * v; }
+      for (int j = 0; j < 3; ++j) { const double v = (double)u[j]; s += cq[12 + j] * v * v; }
       Jacc += 0.5 * s;
     }
     rocket_knot_state<MD, MP, T>(a, kc, x, u, y, ra.okall ? &okk : nullptr);
     if (a.y.ok()) {
+      auto c = a.y.cursor(kc);
 #pragma unroll
-      for (int i = 0; i < 12; ++i) a.y.at(i, kc) = y[i];
+      for (int i = 0; i < 12; ++i) c.put(y[i]);
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) x[i] = y[i];
@@ -763,7 +775,7 @@ template <class MD, class MP, class T> OD_HD void unit_rocket_rollout(const Rock
   if (ra.J) {
     double s = 0.0;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) { const double v = (double)x[i] - cx[i]; s += ra.cqt[i] * v * v; }
+    for (int i = 0; i < 12; ++i) { const double v = (double)x[i] - ra.cxref[i]; s += ra.cqt[i] * v * v; }
     ra.J[p] = Jacc + 0.5 * s;
   }
   if (ra.okall) ra.okall[p] = okk;

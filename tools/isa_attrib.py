@@ -7,9 +7,9 @@ want = set(sys.argv[3:])
 csrc = os.path.join(ROOT, "optimization_dynamics_amd", "csrc")
 out = "/tmp/isa_g_%s.s" % model
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-gline-tables-only", "-S", "--cuda-device-only", "-o", out,
-                       os.path.join(csrc, "od_model_%s.hip" % model)], stderr=subprocess.DEVNULL, cwd=csrc)
+                       os.path.join(csrc, "od_rocket.hip" if model == "rocket" else "od_model_%s.hip" % model)], stderr=subprocess.DEVNULL, cwd=csrc)
 txt = open(out).read()
-files = {int(m.group(1)): m.group(3) for m in re.finditer(r'\.file\t(\d+) "([^"]*)" "([^"]*)"', txt)}
+files = {int(m.group(1)): (m.group(3) or m.group(2)) for m in re.finditer(r'\.file\t(\d+) "([^"]*)"(?: "([^"]*)")?', txt)}
 # function line ranges per file: a crude scan for definitions at brace depth <= 2
 def func_ranges(path):
     res = []
@@ -32,7 +32,7 @@ def func_of(fid, line):
         else: break
     return best
 m = re.search(r"^(_ZN2od\d+%s\w*):" % kern, txt, re.M)
-i = m.start(); j = txt.index("s_endpgm", i)
+i = m.start(); j = txt.index(".Lfunc_end", i)
 cur = "entry"; loc = (0, 0)
 acc = collections.defaultdict(collections.Counter)
 for l in txt[i:j].split("\n"):

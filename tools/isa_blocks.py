@@ -10,7 +10,7 @@ subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-
                       stderr=subprocess.DEVNULL)
 txt = open(out).read()
 m = re.search(r"^(_ZN2od\d+%s\w+):" % kern, txt, re.M)
-i = m.start(); j = txt.index("s_endpgm", i)
+i = m.start(); j = txt.index(".Lfunc_end", i)
 blocks = []; cur = ("entry", [])
 for l in txt[i:j].split("\n"):
     mm = re.match(r"^(\.LBB\w+):", l)

@@ -9,11 +9,11 @@ verbose = "-v" in sys.argv
 csrc = os.path.join(ROOT, "optimization_dynamics_amd", "csrc")
 out = "/tmp/isa_g_%s.s" % model
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-gline-tables-only", "-S", "--cuda-device-only", "-o", out,
-                       os.path.join(csrc, "od_model_%s.hip" % model)] + os.environ.get("EXTRA", "").split(), stderr=subprocess.DEVNULL, cwd=csrc)
+                       os.path.join(csrc, "od_rocket.hip" if model == "rocket" else "od_model_%s.hip" % model)] + os.environ.get("EXTRA", "").split(), stderr=subprocess.DEVNULL, cwd=csrc)
 txt = open(out).read()
-files = {int(m.group(1)): m.group(3) for m in re.finditer(r'\.file\t(\d+) "([^"]*)" "([^"]*)"', txt)}
+files = {int(m.group(1)): (m.group(3) or m.group(2)) for m in re.finditer(r'\.file\t(\d+) "([^"]*)"(?: "([^"]*)")?', txt)}
 m = re.search(r"^(_ZN2od\d+%s\w*):" % kern, txt, re.M)
-i = m.start(); j = txt.index("s_endpgm", i)
+i = m.start(); j = txt.index(".Lfunc_end", i)
 cur, loc, ins = "entry", (0, 0), []
 for l in txt[i:j].split("\n"):
     mm = re.match(r"^(\.LBB\w+):", l)
