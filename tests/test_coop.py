@@ -160,7 +160,7 @@ def _edge_check(lib, device, name, kw):
     bound = 1e-4 if noise_level else 1e-6
     e_all = np.abs(ref[0] - got[0]).max(0)
     # a knot on which the two kernels land apart is a failure unless the lane-per-problem kernel does not reproduce
-    # ITSELF there: 16 copies of the knot with inputs perturbed by 1e-13 relative (several roots within reach of a long
+    # ITSELF there: 16 copies of the knot with inputs perturbed by 1e-13 / 1e-11 relative (several roots within reach of a long
     # Newton path -- tests/parity_checks.py::comparable_states does the same with the oracle)
     sel = same & fin
     im = P.make_im(name, lib, device)
@@ -168,11 +168,12 @@ def _edge_check(lib, device, name, kw):
     im.set_cooperative(1)
     for i in np.nonzero(sel & ~(e_all < bound))[0]:
         rng = np.random.default_rng(int(i))
-        Xp = X[:, [i]] * (1 + 1e-13 * rng.normal(size=(X.shape[0], 16)))
-        Up = U[:, [i]] * (1 + 1e-13 * rng.normal(size=(U.shape[0], 16)))
-        Dp = im.step(torch.tensor(Xp, device=device), torch.tensor(Up, device=device))[0].cpu().numpy()
-        if np.ptp(Dp, axis=1).max() > 10 * bound:
-            sel[i] = False
+        for eps_p in (1e-13, 1e-11):
+            Xp = X[:, [i]] * (1 + eps_p * rng.normal(size=(X.shape[0], 16)))
+            Up = U[:, [i]] * (1 + eps_p * rng.normal(size=(U.shape[0], 16)))
+            Dp = im.step(torch.tensor(Xp, device=device), torch.tensor(Up, device=device))[0].cpu().numpy()
+            if np.ptp(Dp, axis=1).max() > 10 * bound:
+                sel[i] = False
     assert (same & fin & ~sel).sum() <= 1
     e = e_all[sel]
     assert np.median(e) < 1e-12 and e.max() < bound, (kw, np.median(e), e.max())

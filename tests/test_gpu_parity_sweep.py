@@ -49,10 +49,14 @@ def test_parity_sweep(oracle, gpu_lib):
             path_dependent = np.zeros(B, bool)
             for i in np.nonzero(ok & (srel_all >= P.STATE_TOL))[0]:
                 rng = np.random.default_rng(int(i))
-                Xp = X[:, [i]] * (1 + 1e-13 * rng.normal(size=(X.shape[0], 16)))
-                Up = U[:, [i]] * (1 + 1e-13 * rng.normal(size=(U.shape[0], 16)))
-                Dp = oracle.step_grad_batch(P.make_sim(oracle, name), Xp, Up)[0]
-                path_dependent[i] = (np.ptp(Dp, axis=1).max() / max(1e-2, np.abs(Do[:, i]).max())) > 10 * P.STATE_TOL
+                # (1e-13 and 1e-11: the two implementations eliminate in different orders, their iterates differ by up to ~1e-12 on
+                # ill-conditioned knots -- an oracle that is steady under 1e-13 and scatters over a dozen roots under 1e-11 was seen
+                # on one knot of the seed soak, 58 iterations, host build and GPU agreeing with each other to the last bit)
+                for eps_p in (1e-13, 1e-11):
+                    Xp = X[:, [i]] * (1 + eps_p * rng.normal(size=(X.shape[0], 16)))
+                    Up = U[:, [i]] * (1 + eps_p * rng.normal(size=(U.shape[0], 16)))
+                    Dp = oracle.step_grad_batch(P.make_sim(oracle, name), Xp, Up)[0]
+                    path_dependent[i] |= (np.ptp(Dp, axis=1).max() / max(1e-2, np.abs(Do[:, i]).max())) > 10 * P.STATE_TOL
             ok = ok & ~path_dependent
             srel = srel_all[ok]
             grel = W.grad_rel_err(np.concatenate([DX, DU], 1), np.concatenate([DXo, DUo], 1))[ok]
