@@ -234,7 +234,7 @@ def test_rollout_with_finite_undercut(oracle, emu_lib):
 
 
 @pytest.mark.parametrize("name", ["acrobot_impact", "hopper", "cartpole_friction", "planar_push"])
-def test_lane_cooperation_in_lockstep_rows(emu_lib, name):
+def test_lane_cooperation_in_lockstep_rows(oracle, emu_lib, name):
     """The lane cooperation of the lane-per-problem kernels (od_solver.h: cone / orthant step-length tests shared out
     over the 16/ppw copies of a problem, parallel line search; DPP row rotations on the device) on the CPU: the host
     build runs the 16 threads of a row as 16 host threads that meet at every rotation (tests/host_emu/hip/hip_runtime.h),
@@ -259,6 +259,13 @@ def test_lane_cooperation_in_lockstep_rows(emu_lib, name):
             cur = im.step_grad(torch.tensor(X), torch.tensor(U))
             assert torch.equal(ref[3], cur[3]) and torch.equal(ref[4], cur[4]), ppw
             assert torch.equal(ref[0], cur[0]), ppw
-            assert torch.equal(ref[1], cur[1]) and torch.equal(ref[2], cur[2]), ppw      # (same iterates, the same gradient pass)
+            # gradients: bit for bit where the recorded iterates are (the same gradient pass); where the cone variables of the
+            # iterate differ in their last bits between the cooperating and the sequential mapping (hopper, one knot of seed set
+            # 15: 7e-8 relative), both within what the conditioning of THAT knot explains of the exact gradient (binary128
+            # arbiter at this mapping's iterates) -- as tests/test_gpu_parity.py::test_launch_mappings_agree does on the device
+            if not (torch.equal(ref[1], cur[1]) and torch.equal(ref[2], cur[2])):
+                nq = X.shape[0] // 2
+                G = lambda c: np.concatenate([c[1].numpy()[nq:], c[2].numpy()[nq:]], 1)
+                P.assert_grad_conditioned(oracle, im, name, X, U, G(cur), G(ref), ((cur[3] & 3) == 3).numpy(), "mapping %d" % ppw)
     finally:
         emu_lib.cdll.od_emu_set_lockstep(0)
