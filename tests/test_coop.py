@@ -176,7 +176,8 @@ def _edge_check(lib, device, name, kw):
             Xp = X[:, [i]] * (1 + eps_p * rng.normal(size=(X.shape[0], 16)))
             Up = U[:, [i]] * (1 + eps_p * rng.normal(size=(U.shape[0], 16)))
             Dp = im.step(torch.tensor(Xp, device=device), torch.tensor(Up, device=device))[0].cpu().numpy()
-            if np.ptp(Dp, axis=1).max() > 10 * bound:
+            # (... by as much as the two kernels differ: a scatter of a third of the difference or more explains it)
+            if np.ptp(Dp, axis=1).max() > max(10 * bound if eps_p < 1e-12 else 0.0, e_all[i] / 3.0):
                 sel[i] = False
     assert (same & fin & ~sel).sum() <= 1
     e = e_all[sel]
