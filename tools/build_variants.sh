@@ -24,3 +24,11 @@ mkdir -p ../../variants/build_its
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -fno-slp-vectorize -DOD_EXPERIMENT_ITERS_IN_STATUS -c od_rocket.hip -o ../../variants/build_its/od_rocket.o
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../variants/libod_itstat.so $(ls build/*.o | grep -v od_rocket) ../../variants/build_its/od_rocket.o
 echo "variants/libod_itstat.so: OD_LIB=variants/libod_itstat.so python tools/diag_config5_rollout.py 3"
+# the rocket rollout kernels held to 2 / 3 wavefronts per SIMD (256 / 168 registers; tools/sweep_rocket_ppw.py): slower than the
+# 358-register build at every mapping
+for occ in 2 3; do
+mkdir -p ../../variants/build_occ$occ
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -fno-slp-vectorize -DOD_EXPERIMENT_ROLLOUT_OCC=$occ -c od_rocket.hip -o ../../variants/build_occ$occ/od_rocket.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../variants/libod_rollout_occ$occ.so $(ls build/*.o | grep -v od_rocket) ../../variants/build_occ$occ/od_rocket.o
+done
+echo "variants/libod_rollout_occ2.so: OD_LIB=variants/libod_rollout_occ2.so python tools/sweep_rocket_ppw.py"

@@ -5,7 +5,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ilqr_checks as C
 import optimization_dynamics_amd as od
 dev = torch.device("cuda", 0)
-lib = od.default_library()
+from optimization_dynamics_amd import _lib as _L
+lib = _L.Library(os.environ["OD_LIB"]) if os.environ.get("OD_LIB") else od.default_library()
 B, T, n_it = 4096, 60, 10
 for which in ("ex", "hover"):
   for dtype in (torch.float32, torch.float64):
