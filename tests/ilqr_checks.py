@@ -102,17 +102,19 @@ def check_backward_sizes(lib, device, sizes=((12, 3), (8, 2), (4, 1), (10, 2), (
             dV = torch.empty(2, B, dtype=torch.float64, device=device); st = torch.empty(B, dtype=torch.int32, device=device)
             args = [col(A), col(Bm), col(lxx), col(luu), col(lux), dev(lx), dev(lu), col(Vxx), dev(Vx)]
             im._use_current_stream()
-            # the workgroup kernels (matrices in LDS) first, then the default: one trajectory per 16-lane DPP row where m <= 4
+            # the workgroup kernels (matrices in LDS) first, then one trajectory per 16-lane DPP row where m <= 4 (mode 2), then the
+            # default (mode 0): the matrix-core kernel for (12, 3) -- 4 / 8 / 16 trajectories per workgroup by batch size --, the row kernel else
             im.set_cooperative(1)
             lib.check(lib.cdll.od_ilqr_backward(im._h, B, T, n, m, *[_ptr(a) for a in args], 1e-6, _ptr(K), _ptr(k), _ptr(dV), _ptr(st)))
             assert (st == 1).all(), (n, m, B)
             Kl, kl, dVl = K.clone(), k.clone(), dV.clone()
-            im.set_cooperative(0)
-            K.zero_(); k.zero_(); dV.zero_(); st.zero_()
-            lib.check(lib.cdll.od_ilqr_backward(im._h, B, T, n, m, *[_ptr(a) for a in args], 1e-6, _ptr(K), _ptr(k), _ptr(dV), _ptr(st)))
-            assert (st == 1).all(), (n, m, B)
             rel = lambda x, y: ((x - y).abs().max() / y.abs().max().clamp(min=1.0)).item()
-            assert rel(K, Kl) < 1e-10 and rel(k, kl) < 1e-10 and rel(dV, dVl) < 1e-10, (n, m, B, rel(K, Kl), rel(k, kl), rel(dV, dVl))
+            for mode in (2, 0):
+                im.set_cooperative(mode)
+                K.zero_(); k.zero_(); dV.zero_(); st.zero_()
+                lib.check(lib.cdll.od_ilqr_backward(im._h, B, T, n, m, *[_ptr(a) for a in args], 1e-6, _ptr(K), _ptr(k), _ptr(dV), _ptr(st)))
+                assert (st == 1).all(), (n, m, B, mode)
+                assert rel(K, Kl) < 1e-10 and rel(k, kl) < 1e-10 and rel(dV, dVl) < 1e-10, (n, m, B, mode, rel(K, Kl), rel(k, kl), rel(dV, dVl))
             Kh, kh, dVh = K.cpu().numpy(), k.cpu().numpy(), dV.cpu().numpy()
             for b in sorted({0, 1, B // 2, B - 2, B - 1}):
                 mv = lambda M: np.moveaxis(M[..., b], -1, 0)        # (r, c, T) -> (T, r, c)
@@ -185,6 +187,37 @@ def check_one_bad_trajectory_does_not_hurt_the_batch(lib, device, B=4, T=20):
     keep = [0, 2, 3]
     assert torch.isfinite(bad[2][keep]).all()
     assert torch.equal(bad[1][:, :, keep], good[1][:, :, keep]) and torch.equal(bad[2][keep], good[2][keep])
+
+
+def check_backward_retry(lib, device, B=24, T=20, dtype=torch.float64):
+    """a control cost that is indefinite until Quu is regularised by ~0.2: every trajectory's Riccati pass fails at the initial
+    regularisation and repeats ITS recursion at 10 x reg inside the kernel (od_ilqr_solver.inc) until it factorises -- the matrix-core
+    kernel (whole workgroup repeats, mode 0) against the one-trajectory-per-16-lanes kernel (mode 2): same regularisation reached, same
+    gains to rounding; trajectory 1 carries a NaN control and must end with zero gains in both"""
+    dyn, obj0, x1, U0 = rocket_problem(lib, device, B, T, dtype=dtype, seed=5)
+    goal = np.zeros(12); goal[2] = 2.0
+    obj = IL.QuadraticObjective(np.diag([1e-2] * 12), np.diag([-0.2, 1e-2, 1e-3]), np.diag([10.0] * 12), x_ref=goal, device=device)
+    U0 = U0.copy(); U0[:, 3, 1] = np.nan
+    x1t, Ut = torch.tensor(x1, device=device), torch.tensor(U0, device=device)
+    out = {}
+    for mode in (2, 0):
+        dyn.info.set_cooperative(mode) if hasattr(dyn, "info") and hasattr(dyn.info, "set_cooperative") else lib.check(lib.cdll.od_set_cooperative(dyn._h, mode))
+        d = IL.ILQR(dyn, obj, T).device_solver(B, max_iter=1, obj_tol=0.0)
+        d.init(x1t, Ut); d.iterate(1)
+        X, U, J, K, k = d.get(gains=True)
+        out[mode] = (K.double().clone(), k.double().clone(), 0)
+    lib.check(lib.cdll.od_set_cooperative(dyn._h, 0))
+    (K2, k2, r2), (K0, k0, r0) = out[2], out[0]
+    keep = [b for b in range(B) if b != 1]
+    # (without regularisation beyond the initial 1e-6 no trajectory factorises: the one-pass entry point says so)
+    sol = IL.ILQR(dyn, obj, T)
+    Xn, An, Bn, _ = sol.linearize(x1t, Ut)
+    bst = sol.backward(An, Bn, obj.expansion(Xn, Ut.double(), None, 0.0), 1e-6)[3]
+    assert (bst[keep] == 0).all()
+    assert torch.isfinite(K0[..., keep]).all() and K0[..., keep].abs().max() > 0
+    tol = 1e-9 if dtype == torch.float64 else 1e-5
+    assert ((K0 - K2)[..., keep].abs().max() <= tol * K2[..., keep].abs().max()).item() and ((k0 - k2)[..., keep].abs().max() <= tol * k2[..., keep].abs().max().clamp(min=1.0)).item()
+    assert (K0[..., 1] == 0).all() and (k0[..., 1] == 0).all() and (K2[..., 1] == 0).all()
 
 
 def rocket_problem(lib, device, B, T, dtype=torch.float64, seed=0):

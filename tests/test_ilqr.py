@@ -2,6 +2,7 @@
 consistency, and a decreasing cost on cartpole with joint friction -- CPU tier on the host emulation,
 GPU tier through the shipped library."""
 import pytest
+import torch
 
 import ilqr_checks as C
 
@@ -26,10 +27,21 @@ def test_one_bad_trajectory_does_not_hurt_the_batch_gpu(gpu_lib):
 @pytest.mark.gpu
 def test_backward_every_size_instantiation_gpu(gpu_lib):
     C.check_backward_sizes(gpu_lib, "cuda:0")
+    C.check_backward_sizes(gpu_lib, "cuda:0", sizes=((12, 3),), batches=(1030, 2047, 2049), T=7)      # the matrix-core kernel at 8 and 16 trajectories per workgroup, ragged
 
 
 def test_backward_sizes_cpu(emu_lib):
     C.check_backward_sizes(emu_lib, "cpu", sizes=((12, 3), (6, 2)), batches=(5,), T=4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_backward_retry_gpu(gpu_lib, dtype):
+    C.check_backward_retry(gpu_lib, "cuda:0", dtype=dtype)
+
+
+def test_backward_retry_cpu(emu_lib):
+    C.check_backward_retry(emu_lib, "cpu", B=6, T=8)
 
 
 @pytest.mark.gpu

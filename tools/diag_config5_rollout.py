@@ -52,3 +52,25 @@ for a in range(na):
           un[:, a].mean().item(), un[:, a].max().item(), w.mean().item(), w.max().item(), ia.mean(dim=1).sum().item()), file=out)
 h = torch.bincount(it.reshape(-1).long(), minlength=101).cpu().numpy()
 print("histogram of iteration counts (count : knots):", {i: int(c) for i, c in enumerate(h) if c}, file=out)
+
+# ---- what other assignments of candidates to wavefronts would need (the launch ends with its slowest wavefront when every
+# wavefront has a SIMD of its own: <= 1024 wavefronts) ----
+def lockstep(groups):            # groups: (T, nw, lanes) trips, zero-padded
+    w = groups.max(dim=2).values.sum(dim=0)
+    return w.shape[0], w.mean().item(), w.max().item()
+def padded(x, lanes):            # x: (T, N) -> (T, ceil(N / lanes), lanes)
+    N = x.shape[1]; nw = (N + lanes - 1) // lanes
+    y = torch.zeros(x.shape[0], nw * lanes, dtype=x.dtype, device=x.device); y[:, :N] = x
+    return y.reshape(x.shape[0], nw, lanes)
+tot = it + (itd if (cst >> 8).any() else 0) * 0.5            # a dynamics iteration is roughly half a projection iteration
+print("assignment of the %d candidates to wavefronts: wavefronts, mean / max of sum_t max_lanes (projection trips; with the dynamics trips at half weight)" % P, file=out)
+for name, lanes in (("64 consecutive problems of one step size (shipped)", 64), ("48 of one step size", 48), ("44 of one step size", 44), ("32 of one step size", 32)):
+    g = padded(it.reshape(T, P), lanes); g2 = padded(tot.reshape(T, P), lanes)
+    a1, a2 = lockstep(g), lockstep(g2)
+    print("  %-60s %5d  %7.1f %7.1f   (%7.1f %7.1f)" % (name, a1[0], a1[1], a1[2], a2[1], a2[2]), file=out)
+for G in (5, 4, 3, 2, 1):
+    def by_problem(x):           # (T, na, B) -> (T, B / G, G * na): all step sizes of G problems share a wavefront
+        y = x.permute(0, 2, 1).reshape(T, B * na)
+        return padded(y, G * na)
+    a1, a2 = lockstep(by_problem(it)), lockstep(by_problem(tot))
+    print("  %-60s %5d  %7.1f %7.1f   (%7.1f %7.1f)" % ("all %d step sizes of %d problems" % (na, G), a1[0], a1[1], a1[2], a2[1], a2[2]), file=out)
