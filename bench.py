@@ -404,7 +404,8 @@ def main():
                        "total_batch": world * args.batch if args.scaling == "weak" else args.batch,
                        "units_per_step_per_gpu": units_per_rank, "parallelism": "rollouts sharded x%d, no collective%s" % (world, " + all-gather(x+, dq3) compact" if args.gather else "")},
             # the governing roof is the fp64 VECTOR-ALU rate (78.6 TFLOP/s, equal to the fp64 matrix peak on MI355X): the
-            # path is arithmetic on 4..20-wide systems with no GEMM-shaped work, nothing here runs on MFMA
+            # path is arithmetic on 4..20-wide systems with no GEMM-shaped work; the one GEMM-shaped kernel of the repository is the
+            # Riccati pass of the rocket's iLQR iteration (aux_config_5), which does run on MFMA
             "roofline": {"bound": "fp64-valu", "bound_detail": "fp64 vector ALU roof; algorithmic flops of the reference's dense-LU algorithm (SURVEY.md 8d) over the kernel time -- the device executes a sparse elimination, so this is a useful-work ratio",
                          "achieved": ach_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / FP64_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_note": "%s; algorithmic = %d" % (traffic_note, algorithmic_bytes_per_unit() * units_per_rank),

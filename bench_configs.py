@@ -200,18 +200,52 @@ def _config5_one(dev, which, dtype, cpu):
     return out, J, (X, U)
 
 
+def _riccati_pass(dev, B=4096, T=60, reps=20):
+    """od_ilqr_backward alone at config 5's size (n = 12, m = 3, 4096 trajectories x 60 knots, per-knot Hessians as the C entry point
+    takes them): k_ilqr_backward_mfma, the one GEMM-shaped kernel of the path -- HIP events around `reps` launches; HBM and MFMA rooflines"""
+    import ilqr_checks as C
+    import optimization_dynamics_amd as od
+    dyn, obj, x1, U0 = C.rocket_problem(od.default_library(), dev, B, T, dtype=torch.float64, seed=1)
+    x1t, Ut = torch.tensor(x1, device=dev), torch.tensor(U0, device=dev)
+    sol = od.ILQR(dyn, obj, T)
+    X, A, Bm, st = sol.linearize(x1t, Ut)
+    quad = obj.expansion(X, Ut, torch.zeros(12, B, dtype=torch.float64, device=dev), 1.0)
+    sol.backward(A, Bm, quad, 1e-6); torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        K, k, dV, bst = sol.backward(A, Bm, quad, 1e-6)
+    e1.record(); torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / reps
+    n, m = 12, 3
+    per_knot_in, per_knot_out = 8 * (n * n + n * m + n + m + n * n + m * m + m * n), 8 * (m * n + m)
+    bytes_launch = float(T * B * (per_knot_in + per_knot_out))
+    F_alg = T * B * (2.0 * (2 * n ** 3 + 2 * n * n * m + n * m * m) + 2.0 * n * n * m + m ** 3 / 3.0)
+    F_mfma = T * B * 9 * 2.0 * 16 * 16 * 4
+    return dict(workload="od_ilqr_backward, n = 12, m = 3, %d trajectories x %d knots, fp64, per-knot Hessians" % (B, T),
+                kernel="k_ilqr_backward_mfma<double, true, 16> (v_mfma_f64_16x16x4_f64: 9 per knot and trajectory; one wavefront per trajectory, 16 per workgroup, knots staged through LDS)",
+                ms=ms, factorised=int((bst == 1).sum().item()), algorithmic_bytes_per_launch=bytes_launch, algorithmic_bytes_per_knot=per_knot_in + per_knot_out,
+                roofline=dict(bound="hbm", achieved=bytes_launch / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=bytes_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS),
+                mfma=dict(executed_tflops=F_mfma / (ms * 1e-3) / 1e12, algorithmic_tflops=F_alg / (ms * 1e-3) / 1e12, peak=PEAK_TFLOPS["f64"],
+                          executed_frac=F_mfma / (ms * 1e-3) / 1e12 / PEAK_TFLOPS["f64"],
+                          note="16 x 16 x 4 tiles on 12 x 12 / 12 x 3 blocks: 1.9 x the algorithmic flops; tools/ubench/mfma_f64.hip measures 27 ns per MFMA per SIMD (77 TFLOP/s)"))
+
+
 def config5(dev, cpu=True):
     out = dict(workload="rocket soft landing, thrust-cone SOCP projection inside the dynamics (f_rocket_proj and its implicit gradients), iLQR iteration on the "
                         "device (od_ilqr_iterate: expansion, Riccati pass with regularisation retry, closed-loop rollouts of 11 step sizes, cost, Armijo "
                         "selection, copy, linearisation, bookkeeping -- no host synchronisation), 4096 problems, T = 61",
-               kernels="k_rocket_rollout<T> (closed loop, 45 056 candidates) + k_ilqr_backward_row<12, 3, T> + k_rocket<T> (61 440 x f+fx+fu) + k_quad_cost<T, 12, 3> + k_il_*")
+               kernels="k_rocket_rollout<T> (closed loop, 45 056 candidates) + k_ilqr_backward_mfma<T> (Riccati pass on v_mfma_f64_16x16x4_f64, one wavefront per trajectory) + k_rocket<T> (61 440 x f+fx+fu) + k_quad_cost<T, 12, 3> + k_il_*")
     for which in ("examples/rocket.jl inputs", "hover-thrust test problem"):
         for dtype in (torch.float32, torch.float64):
             key = "%s, %s" % (which, "fp32" if dtype == torch.float32 else "fp64")
             r, J, _ = _config5_one(dev, which, dtype, cpu)
             r["cost_mean_after_10_iterations"] = float(J.mean().item())
             out[key] = r
-    # latency floor: one wavefront of problems
+    try:
+        out["riccati_pass"] = _riccati_pass(dev)
+    except Exception as e:
+        out["riccati_pass"] = {"error": repr(e)}
     if cpu:
         from oracle import oracle as O
         import ilqr_checks as C

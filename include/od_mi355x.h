@@ -111,7 +111,8 @@ int od_set_launch_config(od_handle h, int ppw, int waves_per_block);
  * 2 = always where the model has them (the 16-lane form where it has both), 3 = always, the 8-lane form first.
  * Results agree with the lane-per-problem kernels to rounding; which kernel the automatic mode picks depends on the batch
  * size, so pin a mode where results must not depend on it at rounding level.  od_ilqr_backward follows the same switch: mode 1
- * keeps its workgroup (LDS) kernels, any other mode takes the one-trajectory-per-16-lanes kernel where it exists (m <= 4). */
+ * keeps its workgroup (LDS) kernels, modes 2 and 3 take the one-trajectory-per-16-lanes kernel where it exists (m <= 4), mode 0
+ * in addition runs n = 12, m = 3 (the rocket) on the matrix cores, one wavefront per trajectory (batch-minor layout). */
 int od_set_cooperative(od_handle h, int mode);
 /* diagnostics: the iterate at which the last od_step_grad* / od_rollout* call on this handle differentiated each of its
  * K knots -- z at the first iterate satisfying (r_tol, kappa_grad) and, in row nz, the clamp of the orthant variables
@@ -168,7 +169,8 @@ int od_rollout_policy(od_handle h, long B, int T, int nalpha, const void* alphas
 /* Riccati backward pass (Gauss-Newton iLQR) for B trajectories with a per-knot quadratic cost model:
  * A (n x n), Bm (n x m) from od_rollout; lxx (n x n), luu (m x m), lux (m x n), lx (n), lu (m) per knot;
  * VxxT (n x n), VxT (n) per trajectory; reg added to the diagonal of Quu.  Outputs K (m x n), k (m) per knot,
- * dV = [sum k'Qu, sum 1/2 k'Quu k] per trajectory, status 1 = all Quu positive definite.  n <= 16, m <= 12. */
+ * dV = [sum k'Qu, sum 1/2 k'Quu k] per trajectory, status 1 = all Quu positive definite.  n <= 16, m <= 12.
+ * The kernels (od_set_cooperative) agree to rounding, not bit for bit; each gives a trajectory the same bits in any batch. */
 int od_ilqr_backward(od_handle h, long B, int T, int n, int m, const void* A, const void* Bm, const void* lxx,
                      const void* luu, const void* lux, const void* lx, const void* lu, const void* VxxT,
                      const void* VxT, double reg, void* K, void* k, void* dV, int* status);
