@@ -112,7 +112,8 @@ int od_set_launch_config(od_handle h, int ppw, int waves_per_block);
  * Results agree with the lane-per-problem kernels to rounding; which kernel the automatic mode picks depends on the batch
  * size, so pin a mode where results must not depend on it at rounding level.  od_ilqr_backward follows the same switch: mode 1
  * keeps its workgroup (LDS) kernels, modes 2 and 3 take the one-trajectory-per-16-lanes kernel where it exists (m <= 4), mode 0
- * in addition runs n = 12, m = 3 (the rocket) on the matrix cores, one wavefront per trajectory (batch-minor layout). */
+ * runs the models' sizes (n, m) = (12, 3), (8, 2), (10, 2), (4, 1) on the matrix cores, one wavefront per trajectory (batch-minor
+ * layout; csrc/od_ilqr_mfma.inc). */
 int od_set_cooperative(od_handle h, int mode);
 /* diagnostics: the iterate at which the last od_step_grad* / od_rollout* call on this handle differentiated each of its
  * K knots -- z at the first iterate satisfying (r_tol, kappa_grad) and, in row nz, the clamp of the orthant variables
