@@ -223,7 +223,7 @@ def _riccati_pass(dev, B=4096, T=60, reps=20):
     F_alg = T * B * (2.0 * (2 * n ** 3 + 2 * n * n * m + n * m * m) + 2.0 * n * n * m + m ** 3 / 3.0)
     F_mfma = T * B * 9 * 2.0 * 16 * 16 * 4
     return dict(workload="od_ilqr_backward, n = 12, m = 3, %d trajectories x %d knots, fp64, per-knot Hessians" % (B, T),
-                kernel="k_ilqr_backward_mfma<double, true, 16> (v_mfma_f64_16x16x4_f64: 9 per knot and trajectory; one wavefront per trajectory, 16 per workgroup, knots staged through LDS)",
+                kernel="k_ilqr_backward_mfma<12, 3, double, true, 16> (v_mfma_f64_16x16x4_f64: 9 per knot and trajectory; one wavefront per trajectory, 16 per workgroup, knots staged through LDS)",
                 ms=ms, factorised=int((bst == 1).sum().item()), algorithmic_bytes_per_launch=bytes_launch, algorithmic_bytes_per_knot=per_knot_in + per_knot_out,
                 roofline=dict(bound="hbm", achieved=bytes_launch / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=bytes_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS),
                 mfma=dict(executed_tflops=F_mfma / (ms * 1e-3) / 1e12, algorithmic_tflops=F_alg / (ms * 1e-3) / 1e12, peak=PEAK_TFLOPS["f64"],
@@ -235,7 +235,7 @@ def config5(dev, cpu=True):
     out = dict(workload="rocket soft landing, thrust-cone SOCP projection inside the dynamics (f_rocket_proj and its implicit gradients), iLQR iteration on the "
                         "device (od_ilqr_iterate: expansion, Riccati pass with regularisation retry, closed-loop rollouts of 11 step sizes, cost, Armijo "
                         "selection, copy, linearisation, bookkeeping -- no host synchronisation), 4096 problems, T = 61",
-               kernels="k_rocket_rollout<T> (closed loop, 45 056 candidates) + k_ilqr_backward_mfma<T> (Riccati pass on v_mfma_f64_16x16x4_f64, one wavefront per trajectory) + k_rocket<T> (61 440 x f+fx+fu) + k_quad_cost<T, 12, 3> + k_il_*")
+               kernels="k_rocket_rollout<T> (closed loop, 45 056 candidates) + k_ilqr_backward_mfma<12, 3, T, false, 16> (Riccati pass on v_mfma_f64_16x16x4_f64, one wavefront per trajectory) + k_rocket<T> (61 440 x f+fx+fu) + k_quad_cost<T, 12, 3> + k_il_*")
     for which in ("examples/rocket.jl inputs", "hover-thrust test problem"):
         for dtype in (torch.float32, torch.float64):
             key = "%s, %s" % (which, "fp32" if dtype == torch.float32 else "fp64")
