@@ -32,3 +32,14 @@ mkdir -p ../../variants/build_occ$occ
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../variants/libod_rollout_occ$occ.so $(ls build/*.o | grep -v od_rocket) ../../variants/build_occ$occ/od_rocket.o
 done
 echo "variants/libod_rollout_occ2.so: OD_LIB=variants/libod_rollout_occ2.so python tools/sweep_rocket_ppw.py"
+# the matrix-core Riccati kernel (csrc/od_ilqr_mfma.inc) without its 3 x 3 phase (1) / without the loads of the knot loop (2),
+# and with the trajectories per workgroup taken from OD_ILM_W (w): OD_LIB=variants/libod_ilmw.so OD_ILM_W=8 python tools/time_backward.py
+for v in 1 2 w; do
+mkdir -p ../../variants/build_ilm$v
+if [ $v = w ]; then D="-DOD_EXPERIMENT_ILM_W"; else D="-DOD_EXPERIMENT_ILM=$v -DOD_EXPERIMENT_ILM_W"; fi
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value $D -c od_capi.hip -o ../../variants/build_ilm$v/od_capi.o &
+done; wait
+for v in 1 2 w; do
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../variants/libod_ilm$v.so $(ls build/*.o | grep -v od_capi) ../../variants/build_ilm$v/od_capi.o
+done
+echo "variants/libod_ilm{1,2,w}.so: OD_LIB=... OD_ILM_W=4|8|16 OD_BS=64,4096 python tools/time_backward.py"
