@@ -118,6 +118,11 @@ def test_device_iteration_gpu(gpu_lib):
     C.check_device_iteration(gpu_lib, "cuda:0", "cartpole", B=64, T=40)
     C.check_device_iteration(gpu_lib, "cuda:0", "rocket", B=200, T=30, max_iter=6, max_al_iter=1)
     C.check_device_iteration(gpu_lib, "cuda:0", "rocket", B=200, T=30, max_iter=6, max_al_iter=1, dtype=torch.float32)
+    # the matrix-core Riccati kernel at 8 and 16 trajectories per workgroup with the objective's constant Hessians (the solver) against
+    # the same kernel with per-knot Hessians (the host-composed loop), which switches its workgroup size at other batch sizes
+    for B in (1100, 2100):
+        C.check_device_iteration(gpu_lib, "cuda:0", "rocket", B=B, T=12, max_iter=5, max_al_iter=1)
+    C.check_device_iteration(gpu_lib, "cuda:0", "rocket", B=2100, T=12, max_iter=5, max_al_iter=1, dtype=torch.float32)
 
 
 def test_reused_forward_states_cpu(emu_lib):
