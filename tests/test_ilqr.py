@@ -28,6 +28,8 @@ def test_one_bad_trajectory_does_not_hurt_the_batch_gpu(gpu_lib):
 def test_backward_every_size_instantiation_gpu(gpu_lib):
     C.check_backward_sizes(gpu_lib, "cuda:0")
     C.check_backward_sizes(gpu_lib, "cuda:0", sizes=((12, 3),), batches=(1030, 2047, 2049), T=7)      # the matrix-core kernel at 8 and 16 trajectories per workgroup, ragged
+    for T in (1, 2, 3):                                                                               # ... and its prologue / prefetch at the shortest horizons
+        C.check_backward_sizes(gpu_lib, "cuda:0", sizes=((12, 3), (8, 2), (4, 1)), batches=(3, 70), T=T)
 
 
 def test_backward_sizes_cpu(emu_lib):
