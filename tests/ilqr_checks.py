@@ -554,6 +554,64 @@ def check_reference_example(lib, device, which, B=1, need=1.0):
     return info, viol
 
 
+def hopper_example(lib, device, B, seed=1):
+    """examples/hopper.jl, GAIT 1, with the initial configurations held at the example's standing pose: T = 21, h = 0.05, kappa_eval 1e-4,
+    kappa_grad 1e-3 (:12-13, 42); objective of the stages t >= 2 and of the horizon (:205-216: 1/2 (x - x_ref)' 0.1 diag(1, 10, ...) (x - x_ref)
+    + 1/2 0.1 u'u; 1/2 |x - x_ref|^2 at T) around q_ref = [0.5, 0.75 + r_foot, 0, 0.25] (:181); control limits -10 <= u <= 10 at every stage
+    (:224-225, 241-246); the terminal constraint (:248-257) with theta = x1: travel x[1], x[5] >= 0.5 + theta (two inequalities), the other six
+    configuration entries back at theta (equalities) -- one hop forward that ends in the pose it started from; standing controls (:270) as the
+    initial guess; solver options of :277-287.  (The example also optimises theta, through a first stage of its own dimensions 8 -> 16 with
+    nonlinear foot-position constraints (:227-239): that part is beyond the device solver's uniform stages, examples/hopper_gait.py does it
+    with the host loop.)  Problem b > 0 perturbs the initial controls by 1e-2 randn."""
+    from optimization_dynamics_amd.codegen.models import HOPPER_PARAMS as HP
+    h, T = 0.05, 20
+    im = P.make_im("hopper", lib, device)
+    r = HP["foot_radius"]
+    q1 = np.array([0.0, 0.5 + r, 0.0, 0.5]); q_ref = np.array([0.5, 0.75 + r, 0.0, 0.25])
+    x1v, x_ref = np.concatenate([q1, q1]), np.concatenate([q_ref, q_ref])
+    w = np.array([1.0, 10.0, 1.0, 10.0] * 2)
+    obj = IL.QuadraticObjective(0.1 * np.diag(w), 0.1 * np.eye(2), np.eye(8), x_ref=x_ref, device=device)
+    Cs = np.zeros((4, 8)); Ds = np.vstack([-np.eye(2), np.eye(2)]); ds = np.full(4, 10.0)
+    Ct = np.zeros((8, 8)); dt = np.zeros(8)
+    Ct[0, 0] = -1.0; dt[0] = -(0.5 + x1v[0])                    # x_travel - (x[1] - theta[1]) <= 0
+    Ct[1, 4] = -1.0; dt[1] = -(0.5 + x1v[4])
+    for k, i in enumerate([1, 2, 3, 5, 6, 7]):
+        Ct[2 + k, i] = 1.0; dt[2 + k] = x1v[i]
+    obj.set_constraints(stage=(Cs, Ds, ds, 4), terminal=(Ct, dt, 2))
+    U0 = np.zeros((2, T, B)); U0[1] = HP["gravity"] * HP["mass_body"] * 0.5 * h
+    U0[:, :, 1:] += 1e-2 * np.random.default_rng(seed).normal(size=(2, T, B - 1))
+    x1 = np.repeat(x1v[:, None], B, axis=1)
+    opts = dict(max_iter=10, max_al_iter=15, con_tol=1.0e-3, obj_tol=1.0e-3, rho_init=1.0, rho_scale=10.0)
+    return im, obj, x1, U0, x1v, T, opts
+
+
+def check_hopper_example(lib, device, B=1, need=1.0):
+    """the hopper's gait problem (hopper_example) through od_ilqr_solve -- the headline's model inside the device-resident solver, its
+    Riccati pass the 8 / 2 instantiation of the matrix-core kernel: constraints to the example's con_tol, controls inside their limits, the
+    hopper one half metre further in the pose it started from, the returned trajectory consistent with its controls"""
+    im, obj, x1, U0, x1v, T, opts = hopper_example(lib, device, B)
+    sol = IL.ILQR(im, obj, T, alphas=tuple(2.0 ** -i for i in range(17)))
+    x1t, Ut = torch.tensor(x1, device=device), torch.tensor(U0, device=device)
+    X, U, J, hist = sol.solve(x1t, Ut, **opts)
+    info = sol._dev.info()
+    fl, viol, rho = sol._dev.status()
+    okc = viol < opts["con_tol"]
+    assert okc.double().mean().item() >= need, (okc.double().mean().item(), viol.max().item())
+    assert ((fl & 2) != 0).eq(okc).all()
+    assert (U.abs() <= 10.0 + opts["con_tol"]).all()
+    good = okc.nonzero().reshape(-1)
+    XT = X[:, -1, good]
+    assert (XT[0] >= 0.5 - 1e-3).all() and (XT[4] >= 0.5 - 1e-3).all()
+    keep = [1, 2, 3, 5, 6, 7]
+    assert (XT[keep] - torch.tensor(x1v[keep], device=device)[:, None]).abs().max().item() < 1e-3
+    Xr = im.rollout(x1t, U, grads=False)[0]
+    assert (Xr - X).abs().max().item() < 1e-9
+    assert (X[1] > 0.0).all() and (X[5] > 0.0).all()                      # the body stays above the ground
+    print("hopper gait, %d problem(s): %d lockstep iterations, %d multiplier rounds, %.0f %% at con_tol, max violation %.2e, travel %.3f m, objective %.2f .. %.2f"
+          % (B, info.iterations, info.al_iterations, 100 * okc.double().mean().item(), viol.max().item(), XT[4].min().item(), obj.value(X, U).min().item(), obj.value(X, U).max().item()))
+    return info, viol
+
+
 def check_batch_independence(lib, device, problem="cartpole", B=6, T=25, dtype=torch.float64, max_iter=10, max_al_iter=4, pick=(0, 3)):
     """the B problems of a solver are independent solves that share their launches: every trajectory has its own regularisation
     schedule, penalty and flags (csrc/od_ilqr_solver.inc::IlTraj), so what a problem converges to -- trajectory, controls, cost,

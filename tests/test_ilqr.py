@@ -179,3 +179,13 @@ def test_reference_examples_on_the_device_cpu(emu_lib):
 @pytest.mark.parametrize("which", ["cartpole:frictionless", "planar_push:rotate", "planar_push:translate"])
 def test_reference_examples_on_the_device_gpu(gpu_lib, which):
     C.check_reference_example(gpu_lib, "cuda:0", which, B=32, need=0.9)
+
+
+def test_hopper_example_on_the_device_cpu(emu_lib):
+    """examples/hopper.jl's gait problem with the initial configuration fixed, through od_ilqr_solve, one problem (host build)"""
+    C.check_hopper_example(emu_lib, "cpu", B=1)
+
+
+@pytest.mark.gpu
+def test_hopper_example_on_the_device_gpu(gpu_lib):
+    C.check_hopper_example(gpu_lib, "cuda:0", B=64, need=0.9)

@@ -1,5 +1,5 @@
 """The reference's examples solved end to end on the device (od_ilqr_solve), wall time per solve on one MI355X, 1 / 64 / 1024 problems
-(perturbed initial controls): acrobot swing-up, cartpole (frictionless), planar push rotate / translate, rocket landing with the
+(perturbed initial controls): acrobot swing-up, cartpole (frictionless), planar push rotate / translate, the hopper's gait problem (initial configuration fixed), rocket landing with the
 thrust-cone projection and its constraints (fp64 and fp32).  `python tools/time_examples_device.py > profiles/r4_examples_device.json`"""
 import os, sys, time, json, math
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,6 +42,7 @@ for B in (1, 64, 1024):
     run("cartpole frictionless (examples/cartpole.jl)", lambda b: (lambda r: (r[0], r[1], r[2], r[3], r[5], r[6], tuple(2.0 ** -i for i in range(17))))(C.cartpole_example(lib, dev, "frictionless", b)), B)
     for mode in ("rotate", "translate"):
         run("planar push %s (examples/planar_push.jl)" % mode, lambda b, mode=mode: (lambda r: (r[0], r[1], r[2], r[3], r[5], r[6], tuple(2.0 ** -i for i in range(17))))(C.planar_push_example(lib, dev, mode, b)), B)
+    run("hopper gait, initial configuration fixed (examples/hopper.jl)", lambda b: (lambda r: (r[0], r[1], r[2], r[3], r[5], r[6], tuple(2.0 ** -i for i in range(17))))(C.hopper_example(lib, dev, b)), B)
     for dt_ in (torch.float64, torch.float32):
         run("rocket landing, projection + constraints, %s (examples/rocket.jl)" % ("fp64" if dt_ == torch.float64 else "fp32"),
             lambda b, dt_=dt_: (lambda r: (r[0], r[1], r[2], r[3], 60, r[5], r[6]))(C.rocket_example_problem(lib, dev, b, dtype=dt_)), B)
