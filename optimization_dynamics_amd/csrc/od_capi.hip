@@ -1696,7 +1696,7 @@ int od_ilqr_backward(od_handle h, long B, int T, int n, int m, const void* A, co
     if (L == OD_LAYOUT_BATCH_MINOR && h->coop != 1) {        // (od_set_cooperative(h, 1): the LDS kernels below)
       bool done = true;
       const dim3 g = od_grid(B, OD_IL_THREADS / 16), blk(OD_IL_THREADS);
-      if (h->coop == 0 && od_ilm_applies(a)) { OD_HIP(od_ilm_launch<double>(a, h->stream)); return OD_OK; }   // rocket, matrix cores
+      if (h->coop == 0 && od_ilm_applies(a)) { OD_HIP(od_ilm_launch<double>(a, h->stream)); OD_HIP(hipGetLastError()); return OD_OK; }   // rocket, matrix cores
       if (n == 12 && m == 3) hipLaunchKernelGGL((k_ilqr_backward_row<12, 3>), g, blk, 0, h->stream, a);        // rocket
       else if (n == 8 && m == 2) hipLaunchKernelGGL((k_ilqr_backward_row<8, 2>), g, blk, 0, h->stream, a);     // hopper
       else if (n == 4 && m == 1) hipLaunchKernelGGL((k_ilqr_backward_row<4, 1>), g, blk, 0, h->stream, a);     // acrobot, cartpole
