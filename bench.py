@@ -196,11 +196,15 @@ def main():
     ap.add_argument("--ppw", type=int, default=0, help="problems per wavefront (0 = library default)")
     ap.add_argument("--wpb", type=int, default=0, help="wavefronts per workgroup of the solve pass: 1 or 4 (0 = library default)")
     ap.add_argument("--coop", type=int, default=0, help="cooperative solve pass: 0 automatic, 1 never, 2 always")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the multi-rank code path even with ONE rank: torch.distributed.run --nproc-per-node 1, init_process_group "
+                         "(nccl = RCCL on the GPU), barriers, the max-over-ranks all-reduce and (with --gather) all_gather_into_tensor -- so "
+                         "that every line of the N > 1 path has executed on whatever single MI355X is at hand (tests/test_distributed.py)")
     ap.add_argument("--test-emu-lib", default=None,
                     help="TEST HARNESS ONLY (tests/test_distributed.py): run the ranks on CPU over gloo against the host-emulation build")
     args = ap.parse_args()
 
-    if "RANK" not in os.environ and args.gpus > 1:
+    if "RANK" not in os.environ and (args.gpus > 1 or args.force_dist):
         # stand-alone launch: become N ranks (one per GPU) under torch.distributed.run on this node
         cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
                "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
@@ -213,7 +217,7 @@ def main():
         print("bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus = %d" % (args.gpus, world, world), file=sys.stderr)
     emu = args.test_emu_lib is not None
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo" if emu else "nccl")
@@ -265,7 +269,7 @@ def main():
                 X, A, Bm, st, it, out = im.rollout(x1d, Ud, out=out)
                 return st, it
             X, G, st, it, out = im.rollout_compact(x1d, Ud, out=out)
-            if args.gather and world > 1:
+            if args.gather and dist is not None:
                 if gather_bufs is None:
                     gather_bufs = [torch.empty(world * t.numel(), dtype=t.dtype, device=dev) for t in (out["X"], out["G"])]
                 for buf, t in zip(gather_bufs, (out["X"], out["G"])):
@@ -275,7 +279,7 @@ def main():
         for _ in range(args.warmup):
             step()
         sync()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         sync()
         ev = None if emu else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -287,11 +291,11 @@ def main():
             if ev:
                 ev[k][1].record(stream)
         sync()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         sync()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if dist is not None:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
@@ -452,7 +456,7 @@ def main():
             except Exception as e:   # the oracle is a reported baseline, never a dependency of the timed path
                 line["cpu_baseline"] = {"value": None, "unit": "steps+grads/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -235,7 +235,7 @@ def config5(dev, cpu=True):
     out = dict(workload="rocket soft landing, thrust-cone SOCP projection inside the dynamics (f_rocket_proj and its implicit gradients), iLQR iteration on the "
                         "device (od_ilqr_iterate: expansion, Riccati pass with regularisation retry, closed-loop rollouts of 11 step sizes, cost, Armijo "
                         "selection, copy, linearisation, bookkeeping -- no host synchronisation), 4096 problems, T = 61",
-               kernels="k_rocket_rollout<T> (closed loop, 45 056 candidates) + k_ilqr_backward_mfma<12, 3, T, false, 16> (Riccati pass on v_mfma_f64_16x16x4_f64, one wavefront per trajectory) + k_rocket<T> (61 440 x f+fx+fu) + k_quad_cost<T, 12, 3> + k_il_*")
+               kernels="k_rocket_rollout<T> (closed loop, 45 056 candidates) + k_ilqr_backward_mfma<12, 3, T, false, 16> (Riccati pass on v_mfma_f64_16x16x4_f64, one wavefront per trajectory) + k_rocket<T> (245 760 knots x f+fx+fu) + k_quad_cost<T, 12, 3> + k_il_*")
     for which in ("examples/rocket.jl inputs", "hover-thrust test problem"):
         for dtype in (torch.float32, torch.float64):
             key = "%s, %s" % (which, "fp32" if dtype == torch.float32 else "fp64")

@@ -21,6 +21,11 @@
  *    Matrices per problem (dx, du, dz) are column-major inside their E elements, like the reference's
  *    Julia matrices.  For rollouts the problem index of knot t of trajectory b is k = t*B + b.
  *  - Element type is double for OD_F64 handles and float for OD_F32 handles.
+ *  - Devices: a handle belongs to the HIP device that was current when od_create made it (od_get_device).  Every entry point
+ *    that takes the handle (or a solver made from it) switches the calling thread to that device for the duration of the call and
+ *    restores the caller's current device on the way out, so a process that drives several GPUs needs no hipSetDevice around its
+ *    calls.  Pointers passed in must be accessible from the handle's device; a stream of another device is refused
+ *    (OD_ERR_WRONG_DEVICE).
  *  - status bits: 1 = state converged to (r_tol, kappa_eval_tol), 2 = gradient iterate converged to
  *    (r_tol, kappa_grad_tol), 4 = all KKT factorisations were non-singular.
  */
@@ -36,7 +41,7 @@ extern "C" {
 typedef struct od_handle_s* od_handle;
 
 enum od_error {
-  OD_OK = 0, OD_ERR_INVALID = -1, OD_ERR_UNSUPPORTED = -2, OD_ERR_HIP = -3, OD_ERR_NO_DEVICE = -4
+  OD_OK = 0, OD_ERR_INVALID = -1, OD_ERR_UNSUPPORTED = -2, OD_ERR_HIP = -3, OD_ERR_NO_DEVICE = -4, OD_ERR_WRONG_DEVICE = -5
 };
 
 /* model ids: src/models/<model>; hopper is RoboDojo.hopper (examples/hopper.jl:14) */
@@ -75,6 +80,8 @@ int od_default_options(int model, od_options* out);
  * (src/dynamics.jl:51-79): one handle = eval_sim + grad_sim of one model.  opts may be NULL. */
 int od_create(int model, int dtype, const od_options* opts, double h, od_handle* out);
 int od_destroy(od_handle h);
+/* the HIP device the handle lives on (the device that was current in od_create) */
+int od_get_device(od_handle h, int* device);
 int od_set_options(od_handle h, const od_options* opts);
 int od_get_options(od_handle h, od_options* out);
 int od_set_timestep(od_handle h, double dt);
@@ -84,12 +91,16 @@ int od_set_friction(od_handle h, const double* mu, int n);
 int od_set_u_max(od_handle h, double u_max);
 /* The thrust-cone projection (soc_projection, src/models/rocket/dynamics.jl:168-186, eps_min = 0) can stall on the boundary of the
  * cone away from the solution -- accepted step lengths ~1e-13 for the rest of its max_iter iterations, result reported as not
- * converged (status bits 16 / 32 clear), in the CPU oracle alike; ~0.02 % of random controls.  on = 1 (default): such a solve is
- * abandoned once its step length has been below 1e-9 (OD_F32: 1e-5) for 4 consecutive iterations -- status bits as if max_iter
- * had been reached -- so that a lockstep wavefront does not wait ~90 iterations for it.  A solve that does not stall is not
- * touched (bit-identical results).  Of the stalled ones the full loop rescues about a third by accumulated rounding drift (50
- * iterations at alpha ~ 1e-13, then convergence in three steps): with the exit they are reported as not converged instead.
- * on = 0: every iteration, as the reference runs them. */
+ * converged (status bits 16 / 32 clear), in the CPU oracle alike; ~0.02 % of random controls.
+ * on = 0 (DEFAULT): every iteration, as the reference runs them -- od_rocket, od_soc_project and od_rocket_rollout return what the
+ * reference's loop returns, status bits included.
+ * on = 1: such a solve is abandoned once its accepted step length has been below 1e-9 (OD_F32: 1e-3, csrc/od_rocket_proj_direct.h)
+ * for 4 consecutive iterations -- status bits as if max_iter had been reached -- so that a lockstep wavefront does not wait ~90
+ * iterations for it.  A solve that does not stall is not touched (bit-identical results).  Of the stalled ones the full loop
+ * rescues about a third by accumulated rounding drift (50 iterations at alpha ~ 1e-13, then convergence in three steps): with the
+ * exit they are reported as not converged instead; in OD_F32 the 1e-3 threshold also abandons the odd solve that would have
+ * converged late.  The device-resident iLQR solver switches the exit on for its own launches (od_ilqr_options.proj_stall_exit,
+ * default 1: a forward pass is 60 projections deep in lockstep), whatever the handle's setting. */
 int od_set_projection_stall_exit(od_handle h, int on);
 /* OD_F32 rocket handles (BASELINE config 5 asks for single precision): on = 1 (default) finishes every dynamics step with ONE
  * Newton step of the same residual in double at the single-precision solution and takes the implicit gradient -rz^{-1} rtheta
@@ -187,15 +198,19 @@ int od_quad_cost(od_handle h, long P, int T, int n, int m, int dtype, const void
 
 /* ---- the whole iLQR iteration on the device -----------------------------------------------------------
  * iLQR.solver / iLQR.solve! of IterativeLQR.jl as the reference drives it (examples/acrobot.jl:97-113, examples/rocket.jl:118-139)
- * for B independent problems in lockstep: quadratic stage / terminal objective (od_quad_cost) and terminal equality
- * constraints x_T[idx] = goal by augmented Lagrangian (the examples' terminal_con).  One iteration =
- *   expansion of the cost | Riccati backward pass (a trajectory whose Quu + reg I is not positive definite repeats its own
- *   recursion at 10x the regularisation, up to 1e6) | closed-loop rollouts of ALL step sizes of all trajectories | their cost |
- *   Armijo selection per trajectory | copy of the accepted candidate | linearisation (fx, fu) on its states | scalar
- *   bookkeeping (shared regularisation schedule, convergence flag, cost history)
- * -- nine launches on the handle's stream, NO host synchronisation, no allocation: od_ilqr_iterate can be recorded in a HIP
- * graph.  Convergence (max dJ < obj_tol, or reg >= 1e6) sets a flag on the device that turns later iterations into empty
- * launches, so a caller may enqueue max_iter iterations blindly.  The handle may be a mechanical model (n = 2nq, m = nu:
+ * for B independent problems that share their launches: quadratic stage / terminal objective (od_quad_cost); terminal goals
+ * x_T[idx] = goal (od_ilqr_set_objective) and affine stage / terminal equality and inequality rows (od_ilqr_set_constraints) by
+ * augmented Lagrangian.  Every problem has its own regularisation schedule, penalty, convergence flag and constraint flag on the
+ * device and follows the path it would follow in a batch of one.  One iteration =
+ *   Riccati backward pass (a trajectory whose Quu + reg I is not positive definite repeats its own recursion at 10x the
+ *   regularisation, up to 1e6) | closed-loop rollouts of ALL step sizes of all trajectories (the rocket sums their costs on the
+ *   way) | cost of every candidate, its constraint terms | Armijo selection per trajectory | copy of the accepted candidate and
+ *   expansion of the merit on its slots | linearisation (fx, fu) on the states of the trajectories that moved | per-trajectory
+ *   bookkeeping (regularisation x10 / :5, converged if dJ < obj_tol or reg >= 1e6, cost history)
+ * -- six to eight launches on the handle's stream, NO host synchronisation, no allocation: od_ilqr_iterate can be recorded in a
+ * HIP graph.  A converged trajectory drops out of every kernel (rollouts, cost, linearisation -- for the mechanical models the
+ * two passes of od_step_grad are predicated per trajectory like the rocket's kernels); once all have, a flag on the device turns
+ * later iterations into empty launches, so a caller may enqueue max_iter iterations blindly.  The handle may be a mechanical model (n = 2nq, m = nu:
  * od_rollout_policy / od_step_grad underneath) or OD_ROCKET_DYNAMICS in OD_F64 / OD_F32 (n = 12, m = 3: od_rocket_rollout /
  * od_rocket with or without the thrust-cone projection).  Batch-minor layout only.  The solver borrows the handle: no other
  * call on the handle while solver work is in flight, and the handle must outlive the solver. */
@@ -209,6 +224,9 @@ typedef struct {
   int max_iter, max_al_iter;    /* (50, 1)                                                                 */
   int project;         /* rocket handles: 1 = f_rocket_proj (thrust-cone projection on the path), 0 = f_rocket */
   int history;         /* cost histories kept on the device: iterations (0 = max_iter * max_al_iter)      */
+  int proj_stall_exit; /* rocket handles: the solver's own launches abandon stalled thrust-cone projections (1; see
+                          od_set_projection_stall_exit -- the handle's setting is not used by the solver)  */
+  double rho_max;      /* the penalty never grows beyond this (1e8; IterativeLQR's maximum penalty as recalled) */
 } od_ilqr_options;
 typedef struct {
   int iterations;      /* iLQR iterations run since od_ilqr_init (all augmented-Lagrangian rounds)         */
@@ -302,6 +320,11 @@ int od_rocket(od_handle h, long B, int project, const void* x, const void* u, vo
  * interior-point solve the reference uses (z0 and options of :169-175).  uproj: 3; duproj: 3 x 3 col-major
  * d uproj / d u (NULL = diff_sol false); status bits 16 / 32 = state / gradient converged. */
 int od_soc_project(od_handle h, long B, const void* u, void* uproj, void* duproj, int* status);
+/* the same solve with its whole solution: z (10 per problem) = [u_proj (3), p, s, w, y, v (3)] of the projection's KKT system
+ * (src/models/rocket/codegen.jl:45-64) -- the iterate soc_projection_gradient differentiates at (ip.z, dynamics.jl:180-185; the
+ * two tolerances of this solve are equal) -- and iters (1 per problem, may be NULL) the interior-point iterations it took.  Lets a
+ * checker recompute -rz^{-1} rtheta at exactly that point. */
+int od_soc_project_full(od_handle h, long B, const void* u, void* z, void* duproj, int* status, int* iters);
 
 /* iLQR.rollout / forward pass over f_rocket (project = 0) or f_rocket_proj (project = 1), time recursion on the
  * device (examples/rocket.jl:29-41,118).  nalpha = 0: open loop, controls ubar (3 per knot, T*B knots), B

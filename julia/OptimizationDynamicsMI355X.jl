@@ -306,6 +306,7 @@ end
 struct ILQROptions                    # od_ilqr_options
     reg::Cdouble; c1::Cdouble; obj_tol::Cdouble; con_tol::Cdouble; rho_init::Cdouble; rho_scale::Cdouble
     max_iter::Cint; max_al_iter::Cint; project::Cint; history::Cint
+    proj_stall_exit::Cint; rho_max::Cdouble       # (C layout: four bytes of padding before the double, as in the header's struct)
 end
 struct ILQRInfo                       # od_ilqr_info
     iterations::Cint; al_iterations::Cint; done::Cint; al_done::Cint; bad_linearisations::Cint
@@ -325,8 +326,8 @@ constraints x_T[goal_idx] = goal by augmented Lagrangian (cf. iLQR.Options, exam
 """
 function ILQRSolver(dyn, B::Integer, T::Integer; alphas=[2.0^-i for i in 0:10], Q, R, QT, xref,
         goal_idx=Int[], goal=Float64[], reg=1.0e-6, c1=1.0e-4, obj_tol=1.0e-6, con_tol=1.0e-3, max_iter=50, max_al_iter=1,
-        ρ_init=1.0, ρ_scale=10.0, project=true, history=0)
-    o = Ref(ILQROptions(reg, c1, obj_tol, con_tol, ρ_init, ρ_scale, max_iter, max_al_iter, project ? 1 : 0, history))
+        ρ_init=1.0, ρ_scale=10.0, project=true, history=0, proj_stall_exit=true, ρ_max=1.0e8)
+    o = Ref(ILQROptions(reg, c1, obj_tol, con_tol, ρ_init, ρ_scale, max_iter, max_al_iter, project ? 1 : 0, history, proj_stall_exit ? 1 : 0, ρ_max))
     hd = Ref{Ptr{Cvoid}}(C_NULL)
     a = Float64.(collect(alphas))
     check(ccall((:od_ilqr_create, LIB), Cint, (Ptr{Cvoid}, Clong, Cint, Cint, Ptr{Cdouble}, Ref{ILQROptions}, Ref{Ptr{Cvoid}}),
@@ -335,6 +336,9 @@ function ILQRSolver(dyn, B::Integer, T::Integer; alphas=[2.0^-i for i in 0:10], 
     check(ccall((:od_ilqr_set_objective, LIB), Cint, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cint, Ptr{Cint}, Ptr{Cdouble}),
                 hd[], Matrix{Float64}(Q), Matrix{Float64}(R), Matrix{Float64}(QT), Float64.(collect(xref)), length(gi), gi, Float64.(collect(goal))))
     s = ILQRSolver(hd[], dyn, B, T)
+    # (Julia gives no order between this finaliser and the owner's od_destroy when both become unreachable in one sweep: the
+    # library takes either order -- od_destroy releases what its live solvers hold and detaches them, od_ilqr_destroy of a
+    # detached solver only frees the host object)
     finalizer(x -> ccall((:od_ilqr_destroy, LIB), Cint, (Ptr{Cvoid},), x.s), s)
     return s
 end

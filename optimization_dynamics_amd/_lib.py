@@ -31,7 +31,7 @@ class IlqrOptions(C.Structure):
     """od_ilqr_options (cf. iLQR.Options, examples/acrobot.jl:98-107)"""
     _fields_ = [("reg", C.c_double), ("c1", C.c_double), ("obj_tol", C.c_double), ("con_tol", C.c_double),
                 ("rho_init", C.c_double), ("rho_scale", C.c_double), ("max_iter", C.c_int), ("max_al_iter", C.c_int),
-                ("project", C.c_int), ("history", C.c_int)]
+                ("project", C.c_int), ("history", C.c_int), ("proj_stall_exit", C.c_int), ("rho_max", C.c_double)]
 
 
 class IlqrInfo(C.Structure):
@@ -60,6 +60,7 @@ SIGNATURES = {
     "od_default_options": (C.c_int, [C.c_int, C.POINTER(Options)]),
     "od_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(Options), C.c_double, C.POINTER(_VP)]),
     "od_destroy": (C.c_int, [_VP]),
+    "od_get_device": (C.c_int, [_VP, C.POINTER(C.c_int)]),
     "od_set_options": (C.c_int, [_VP, C.POINTER(Options)]),
     "od_get_options": (C.c_int, [_VP, C.POINTER(Options)]),
     "od_set_timestep": (C.c_int, [_VP, C.c_double]),
@@ -103,6 +104,7 @@ SIGNATURES = {
     "od_ip_solve": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _VP, _IP, _IP]),
     "od_rocket": (C.c_int, [_VP, C.c_long, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _IP]),
     "od_soc_project": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _IP]),
+    "od_soc_project_full": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _IP, _IP]),
     "od_model_indices": (C.c_int, [C.c_int, C.c_int, _IP, C.c_int]),
     "od_step_full": (C.c_int, [_VP, C.c_long, _VP, _VP, _VP, _VP, _IP, _IP]),
     "od_rocket_rollout": (C.c_int, [_VP, C.c_long, C.c_int, C.c_int, _VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _IP]),
@@ -167,6 +169,16 @@ class Library:
         o = Options()
         self.check(self.cdll.od_default_options(self.model_id(model), C.byref(o)))
         return o
+
+
+def on_device(device):
+    """context manager: `device` is the current HIP device inside (od_create makes its handle on the current device)"""
+    import contextlib
+    import torch
+    device = torch.device(device)
+    if device.type == "cuda":
+        return torch.cuda.device(device)
+    return contextlib.nullcontext()
 
 
 _default = None

@@ -1,8 +1,11 @@
 // C ABI of libod_mi355x.so (include/od_mi355x.h): argument checking, view construction, launches.
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
+
+#include <vector>
 
 #include "../../include/od_mi355x.h"
 #include "od_vtable.h"
@@ -23,6 +26,29 @@ int fail(int code, const std::string& msg) {
     hipError_t e_ = (call);                                                               \
     if (e_ != hipSuccess) return fail(OD_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
   } while (0)
+
+// A handle lives on the device that was current in od_create.  Every entry point runs on that device: the calling thread's current
+// device is switched for the duration of the call and put back on the way out (the behaviour of a device guard), so that
+// ImplicitDynamics(device = 1) works from a thread whose current device is 0 -- launches, allocations and attribute settings are
+// per device in HIP, and nothing else in this library names one.
+struct OnDevice {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit OnDevice(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) {
+      err = hipSetDevice(dev);
+      switched = err == hipSuccess;
+    }
+  }
+  ~OnDevice() { if (switched) (void)hipSetDevice(prev); }
+  OnDevice(const OnDevice&) = delete;
+  OnDevice& operator=(const OnDevice&) = delete;
+};
+#define OD_ON_DEVICE(h_)                                                                                   \
+  OnDevice od_guard_((h_)->device);                                                                         \
+  if (od_guard_.err != hipSuccess) return fail(OD_ERR_HIP, std::string("switching to the handle's device: ") + hipGetErrorString(od_guard_.err))
 
 const ModelVT* vt_of(int model) {
   switch (model) {
@@ -1125,6 +1151,7 @@ template <class TA> __global__ __launch_bounds__(OD_BLOCK) void k_ilqr_backward_
 
 struct od_handle_s {
   const ModelVT* vt;
+  int device;            // the HIP device that was current in od_create: every entry point runs there (OnDevice)
   int dtype, layout;
   od_options opts;
   double h, fric[4], u_max;
@@ -1142,7 +1169,9 @@ struct od_handle_s {
   double* hstage;  // pinned, device-mapped host staging of od_f_host / od_fx_host / od_fu_host
   double* hstage_dev;
   size_t hstage_elems;
+  std::vector<od_ilqr_s*> solvers;   // live od_ilqr solvers made from this handle (od_destroy releases what they hold)
 };
+static void il_detach_all(od_handle_s* h);      // od_ilqr_solver.inc
 
 namespace {
 
@@ -1240,26 +1269,27 @@ int check_mech(od_handle_s* h, const char* fn) {
 }
 
 // pass 2 over K knots whose states live in `xstate` (slot k) -- shared by od_step_grad and od_rollout
-int run_grad_pass(od_handle_s* h, StepArgs<double> g, long K, View<const double> xstate) {
+int run_grad_pass(od_handle_s* h, StepArgs<double> g, long K, View<const double> xstate, LiveArgs lv = LiveArgs{nullptr, nullptr, 1}) {
   h->grad_knots = K;
   g.B = K;
   g.x = xstate;
   g.d.p = nullptr;
   g.iters.p = nullptr;
-  OD_HIP(h->vt->grad_knots(g, h->stream));
+  OD_HIP(h->vt->grad_knots(g, h->stream, lv));
   return OD_OK;
 }
 
 int run_step(od_handle_s* h, const char* fn, long B, const void* x, const void* u, void* d, void* dx, void* du,
-             void* dq3, int* status, int* iters, int want_grad, void* q3 = nullptr, long x_se = 0) {
+             void* dq3, int* status, int* iters, int want_grad, void* q3 = nullptr, long x_se = 0, LiveArgs lv = LiveArgs{nullptr, nullptr, 1}) {
   if (int rc = check_mech(h, fn)) return rc;
   if (B <= 0) return OD_OK;
   if (!x || (h->vt->nu > 0 && !u)) return fail(OD_ERR_INVALID, std::string(fn) + ": null input");
+  OD_ON_DEVICE(h);
   StepArgs<double> a = step_args(h, B, B, x, u, d, dx, du, dq3, status, iters, want_grad);
   if (x_se) a.x.se = x_se;         // (the states are the first B slots of a longer batch-minor array: od_ilqr_solver.inc)
   a.q3 = mkview<double>(q3, h->vt->nq, B, h->layout);
   if (!want_grad) {
-    OD_HIP(h->vt->step_state(a, cfg_of(h, B), h->stream));
+    OD_HIP(h->vt->step_state(a, cfg_of(h, B), h->stream, lv));
     return OD_OK;
   }
   if (int rc = ensure_work(h, (size_t)(h->vt->nz + 1) * (size_t)B)) return rc;
@@ -1268,17 +1298,17 @@ int run_step(od_handle_s* h, const char* fn, long B, const void* x, const void* 
     // eval_sim and grad_sim iterate differently (finite undercut): run them separately like the reference
     StepArgs<double> e = a;
     e.want_grad = 0;
-    OD_HIP(h->vt->step_state(e, cfg_of(h, B), h->stream));
+    OD_HIP(h->vt->step_state(e, cfg_of(h, B), h->stream, lv));
     StepArgs<double> g = a;
     g.d.p = nullptr;
     g.q3.p = nullptr;
     g.merge_grad_status = 1;
     g.opts.kappa_eval = g.opts.kappa_grad;
-    OD_HIP(h->vt->step_state(g, cfg_of(h, B), h->stream));
+    OD_HIP(h->vt->step_state(g, cfg_of(h, B), h->stream, lv));
   } else {
-    OD_HIP(h->vt->step_state(a, cfg_of(h, B), h->stream));
+    OD_HIP(h->vt->step_state(a, cfg_of(h, B), h->stream, lv));
   }
-  return run_grad_pass(h, a, B, a.x);
+  return run_grad_pass(h, a, B, a.x, lv);
 }
 
 }  // namespace
@@ -1332,16 +1362,20 @@ template <class T> static RocketArgs<T> rocket_args(od_handle h, long B, int pro
   return a;
 }
 
-template <class T> static int soc_project_impl(od_handle h, long B, const void* u, void* uproj, void* duproj, int* status) {
+template <class T> static int soc_project_impl(od_handle h, long B, const void* u, void* uproj, void* duproj, void* zfull, int* status, int* iters) {
   const int L = h->layout;
-  RocketArgs<T> a = rocket_args<T>(h, B, 1, duproj ? 1 : 0);
+  SocProjectArgs<T> sa;
+  RocketArgs<T>& a = sa.a;
+  a = rocket_args<T>(h, B, 1, duproj ? 1 : 0);
   a.u = mkcview<T>(u, 3, B, L);
   a.uproj = mkview<T>(uproj, 3, B, L);
   a.du = mkview<T>(duproj, 9, B, L);
   a.status = mkview<int>(status, 1, B, L);
+  sa.z = mkview<T>(zfull, 10, B, L);
+  sa.iters = mkview<int>(iters, 1, B, L);
   hipError_t e;
-  if constexpr (sizeof(T) == 8) e = launch_soc_project64(a, ppw_of(h, B), h->stream);
-  else e = launch_soc_project32(a, ppw_of(h, B), h->stream);
+  if constexpr (sizeof(T) == 8) e = launch_soc_project64(sa, ppw_of(h, B), h->stream);
+  else e = launch_soc_project32(sa, ppw_of(h, B), h->stream);
   if (e != hipSuccess) return fail(OD_ERR_HIP, std::string("od_soc_project launch: ") + hipGetErrorString(e));
   return OD_OK;
 }
@@ -1452,15 +1486,18 @@ int od_create(int model, int dtype, const od_options* opts, double dt, od_handle
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(OD_ERR_NO_DEVICE, "od_create: no HIP device visible (this library has no CPU path)");
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(OD_ERR_HIP, "od_create: hipGetDevice failed");
   od_handle_s* h = new od_handle_s();
   h->vt = vt;
+  h->device = dev;
   h->dtype = dtype;
   h->layout = OD_LAYOUT_BATCH_MINOR;
   if (opts) h->opts = *opts; else defaults_of(vt, &h->opts);
   h->h = dt;
   for (int i = 0; i < 4; ++i) h->fric[i] = vt->fric_default[i];
   h->u_max = 12.5;   // examples/rocket.jl:16
-  h->proj_stall_exit = 1;
+  h->proj_stall_exit = 0;   // (the reference runs every iteration; od_ilqr_options.proj_stall_exit switches it on for the solver's own launches)
   h->polish64 = 1;
   h->stream = nullptr;
   h->ppw = 0;
@@ -1480,10 +1517,18 @@ int od_create(int model, int dtype, const od_options* opts, double dt, od_handle
 
 int od_destroy(od_handle h) {
   if (!h) return OD_OK;
+  OD_ON_DEVICE(h);
+  il_detach_all(h);
   if (h->stage) (void)hipFree(h->stage);
   if (h->hstage) (void)hipHostFree(h->hstage);
   if (h->work) (void)hipFree(h->work);
   delete h;
+  return OD_OK;
+}
+
+int od_get_device(od_handle h, int* device) {
+  if (!h || !device) return fail(OD_ERR_INVALID, "od_get_device: null argument");
+  *device = h->device;
   return OD_OK;
 }
 
@@ -1530,6 +1575,13 @@ int od_set_layout(od_handle h, int layout) {
 }
 int od_set_stream(od_handle h, void* s) {
   if (!h) return fail(OD_ERR_INVALID, "od_set_stream: null handle");
+  OD_ON_DEVICE(h);
+  if (s && h->stream != (hipStream_t)s) {
+    int sdev = h->device;
+    if (hipStreamGetDevice((hipStream_t)s, &sdev) == hipSuccess && sdev != h->device)
+      return fail(OD_ERR_WRONG_DEVICE, "od_set_stream: the stream belongs to device " + std::to_string(sdev) + ", the handle to device " + std::to_string(h->device));
+    (void)hipGetLastError();
+  }
   if (h->stream != (hipStream_t)s) {
     // the handle's workspaces (gradient hand-over, staging) are shared by consecutive calls: a handle works on one
     // stream at a time, so work queued on the old stream finishes before the new one may reuse them.  If the old stream
@@ -1553,6 +1605,7 @@ int od_set_cooperative(od_handle h, int mode) {
 
 int od_get_grad_iterates(od_handle h, long K, void* out) {
   if (!h || !out || K <= 0) return fail(OD_ERR_INVALID, "od_get_grad_iterates: null handle / buffer");
+  OD_ON_DEVICE(h);
   const size_t n = (size_t)(h->vt->nz + 1) * (size_t)K;
   if (!h->work || h->work_elems < n || h->grad_knots != K)
     return fail(OD_ERR_INVALID, "od_get_grad_iterates: K must be the number of knots of the last gradient pass on this handle (" + std::to_string(h->grad_knots) + ")");
@@ -1571,6 +1624,7 @@ int od_set_launch_config(od_handle h, int ppw, int waves_per_block) {
 }
 int od_synchronize(od_handle h) {
   if (!h) return fail(OD_ERR_INVALID, "od_synchronize: null handle");
+  OD_ON_DEVICE(h);
   OD_HIP(hipStreamSynchronize(h->stream));
   return OD_OK;
 }
@@ -1594,6 +1648,7 @@ static int rollout_impl(od_handle h, const char* fn, long B, int T, const void* 
   if (int rc = check_mech(h, fn)) return rc;
   if (B <= 0 || T <= 0) return OD_OK;
   if (!x1 || !U || !X) return fail(OD_ERR_INVALID, std::string(fn) + ": null x1/U/X");
+  OD_ON_DEVICE(h);
   const int want_grad = (A || Bm || dq3) ? 1 : 0;
   const bool fused = fusable(h);
   const int n = 2 * h->vt->nq, nz = h->vt->nz;
@@ -1625,7 +1680,7 @@ static int rollout_impl(od_handle h, const char* fn, long B, int T, const void* 
     g.want_grad = 1;
     g.merge_grad_status = 1;
     g.opts.kappa_eval = g.opts.kappa_grad;
-    OD_HIP(h->vt->step_state(g, cfg_of(h, K), h->stream));
+    OD_HIP(h->vt->step_state(g, cfg_of(h, K), h->stream, LiveArgs{nullptr, nullptr, 1}));
   }
   return run_grad_pass(h, r.s, K, xin);                                // pass 2: all T*B gradients
 }
@@ -1643,6 +1698,7 @@ int od_rollout_policy(od_handle h, long B, int T, int nalpha, const void* alphas
   if (int rc = check_mech(h, "od_rollout_policy")) return rc;
   if (B <= 0 || T <= 0 || nalpha <= 0) return OD_OK;
   if (!alphas || !x1 || !xbar || !ubar || !K || !kff || !X || !U) return fail(OD_ERR_INVALID, "od_rollout_policy: null argument");
+  OD_ON_DEVICE(h);
   const int n = 2 * h->vt->nq, nu = h->vt->nu, L = h->layout;
   const long P = B * nalpha, Kn = (long)T * B, Kc = (long)T * P;
   PolicyArgs<double> pa;
@@ -1674,6 +1730,7 @@ int od_ilqr_backward(od_handle h, long B, int T, int n, int m, const void* A, co
   if (n <= 0 || m <= 0 || n > OD_IL_N || m > OD_IL_M) return fail(OD_ERR_INVALID, "od_ilqr_backward: n <= 16, m <= 12");
   if (!A || !Bm || !lxx || !luu || !lux || !lx || !lu || !VxxT || !VxT || !K || !k || !dV)
     return fail(OD_ERR_INVALID, "od_ilqr_backward: null argument");
+  OD_ON_DEVICE(h);
   const int L = h->layout;
   const long Kn = (long)T * B;
   IlqrArgs a;
@@ -1813,6 +1870,7 @@ int od_quad_cost(od_handle h, long P, int T, int n, int m, int dtype, const void
   if (T <= 0 || n <= 0 || m <= 0 || n > OD_IL_N || m > OD_IL_M) return fail(OD_ERR_INVALID, "od_quad_cost: T >= 1, n <= 16, m <= 12");
   if (dtype != OD_F64 && dtype != OD_F32) return fail(OD_ERR_INVALID, "od_quad_cost: dtype OD_F64 or OD_F32");
   if (!X || !U || !Q || !R || !QT || !xref || !J) return fail(OD_ERR_INVALID, "od_quad_cost: null argument");
+  OD_ON_DEVICE(h);
   const int L = h->layout;
 #define OD_QC_LAUNCH(T_, N_, M_) hipLaunchKernelGGL((k_quad_cost<T_, N_, M_>), od_grid(P, 64), dim3(256), 0, h->stream, a)
 #define OD_QC_SIZES(T_)                                                                                   \
@@ -1876,6 +1934,7 @@ int od_bundle_grad(od_handle h, long B, int N, const void* x, const void* u, con
   if (B <= 0) return OD_OK;
   if (N <= 0 || !x || !eta || !dz || !ws) return fail(OD_ERR_INVALID, "od_bundle_grad: bad arguments");
   if (ws_bytes < od_bundle_workspace_bytes(h, B, N)) return fail(OD_ERR_INVALID, "od_bundle_grad: workspace too small");
+  OD_ON_DEVICE(h);
   const int nq = h->vt->nq, nzb = 2 * nq + h->vt->nu;
   const long P = (long)(N + 1) * B;
   BundleArgs<double> a;
@@ -1898,6 +1957,7 @@ int od_ls_fit(od_handle h, long B, int N, int ny, int nzb, const void* eta, cons
   if (B <= 0) return OD_OK;
   if (N <= 0 || ny <= 0 || nzb <= 0 || ny > OD_LS_MAX || nzb > OD_LS_MAX || !eta || !feta || !M)
     return fail(OD_ERR_INVALID, "od_ls_fit: bad arguments (ny, nzb <= 24)");
+  OD_ON_DEVICE(h);
   View<const double> fv = mkcview<double>(feta, ny, (long)(N + 1) * B, OD_LAYOUT_BATCH_MINOR);
   if (int rc = ensure_work(h, (size_t)nzb * (nzb + ny) * (size_t)B)) return rc;
   h->grad_knots = 0;                                   // the workspace no longer holds gradient iterates
@@ -1927,6 +1987,7 @@ int od_step_full(od_handle h, long B, const void* x, const void* u, void* z, voi
   if (B <= 0) return OD_OK;
   if (!x || !z || (h->vt->nu > 0 && !u)) return fail(OD_ERR_INVALID, "od_step_full: null x/u/z");
   if (dz && !fusable(h)) return fail(OD_ERR_UNSUPPORTED, "od_step_full: finite undercut with kappa_eval != kappa_grad");
+  OD_ON_DEVICE(h);
   const ModelVT* vt = h->vt;
   FullArgs<double> a;
   a.s = step_args(h, B, B, x, u, nullptr, nullptr, nullptr, nullptr, status, iters, dz ? 1 : 0);
@@ -1940,6 +2001,7 @@ int od_ip_solve(od_handle h, long B, const void* z0, const void* theta, void* z,
   if (!h) return fail(OD_ERR_INVALID, "od_ip_solve: null handle");
   if (B <= 0) return OD_OK;
   if (!z0 || !theta || !z) return fail(OD_ERR_INVALID, "od_ip_solve: null z0/theta/z");
+  OD_ON_DEVICE(h);
   const ModelVT* vt = h->vt;
   const int L = h->layout;
   if (h->dtype == OD_F64) {
@@ -1979,6 +2041,7 @@ int od_rocket_rollout(od_handle h, long B, int T, int nalpha, const void* alphas
   if (B <= 0 || T <= 0) return OD_OK;
   if (!x1 || !ubar || !X) return fail(OD_ERR_INVALID, "od_rocket_rollout: null x1/ubar/X");
   if (nalpha > 0 && (!alphas || !xbar || !K || !kff)) return fail(OD_ERR_INVALID, "od_rocket_rollout: policy arguments missing");
+  OD_ON_DEVICE(h);
   if (h->dtype == OD_F64) return rocket_rollout_impl<double>(h, B, T, nalpha, alphas, project, x1, xbar, ubar, K, kff, X, U, status);
   return rocket_rollout_impl<float>(h, B, T, nalpha, alphas, project, x1, xbar, ubar, K, kff, X, U, status);
 }
@@ -1989,6 +2052,7 @@ int od_rocket(od_handle h, long B, int project, const void* x, const void* u, vo
   if (h->vt->id != OD_ROCKET_DYNAMICS) return fail(OD_ERR_UNSUPPORTED, "od_rocket: needs an OD_ROCKET_DYNAMICS handle");
   if (B <= 0) return OD_OK;
   if (!x || !u) return fail(OD_ERR_INVALID, "od_rocket: null input");
+  OD_ON_DEVICE(h);
   if (h->dtype == OD_F64) return rocket_impl<double>(h, B, project, x, u, y, dx, du, uproj, status);
   return rocket_impl<float>(h, B, project, x, u, y, dx, du, uproj, status);
 }
@@ -1998,8 +2062,19 @@ int od_soc_project(od_handle h, long B, const void* u, void* uproj, void* duproj
   if (h->vt->id != OD_ROCKET_DYNAMICS) return fail(OD_ERR_UNSUPPORTED, "od_soc_project: needs an OD_ROCKET_DYNAMICS handle");
   if (B <= 0) return OD_OK;
   if (!u) return fail(OD_ERR_INVALID, "od_soc_project: null input");
-  if (h->dtype == OD_F64) return soc_project_impl<double>(h, B, u, uproj, duproj, status);
-  return soc_project_impl<float>(h, B, u, uproj, duproj, status);
+  OD_ON_DEVICE(h);
+  if (h->dtype == OD_F64) return soc_project_impl<double>(h, B, u, uproj, duproj, nullptr, status, nullptr);
+  return soc_project_impl<float>(h, B, u, uproj, duproj, nullptr, status, nullptr);
+}
+
+int od_soc_project_full(od_handle h, long B, const void* u, void* z, void* duproj, int* status, int* iters) {
+  if (!h) return fail(OD_ERR_INVALID, "od_soc_project_full: null handle");
+  if (h->vt->id != OD_ROCKET_DYNAMICS) return fail(OD_ERR_UNSUPPORTED, "od_soc_project_full: needs an OD_ROCKET_DYNAMICS handle");
+  if (B <= 0) return OD_OK;
+  if (!u || !z) return fail(OD_ERR_INVALID, "od_soc_project_full: null u / z");
+  OD_ON_DEVICE(h);
+  if (h->dtype == OD_F64) return soc_project_impl<double>(h, B, u, nullptr, duproj, z, status, iters);
+  return soc_project_impl<float>(h, B, u, nullptr, duproj, z, status, iters);
 }
 
 // ---- host scalar path ------------------------------------------------------------------------
@@ -2012,6 +2087,7 @@ static int host_call(od_handle h, const double* x, const double* u, double* d, d
   const int n = 2 * h->vt->nq, nu = h->vt->nu;
   if (!x || (nu > 0 && !u)) return fail(OD_ERR_INVALID, "od_f_host / od_fx_host / od_fu_host: null x / u");
   if (!d && !dx && !du) return fail(OD_ERR_INVALID, "od_f_host / od_fx_host / od_fu_host: no output buffer");
+  OD_ON_DEVICE(h);
   const size_t need = (size_t)n + nu + n + (size_t)n * n + (size_t)n * nu;
   if (h->hstage_elems < need) {
     if (h->hstage) (void)hipHostFree(h->hstage);
@@ -2088,6 +2164,7 @@ template <class T> static int rocket_host_impl(od_handle h, int project, const d
 
 int od_rocket_host(od_handle h, int project, const double* x, const double* u, double* y, double* dx, double* du, double* uproj, int* status) {
   if (!h || !x || !u) return fail(OD_ERR_INVALID, "od_rocket_host: null argument");
+  OD_ON_DEVICE(h);
   if (h->dtype == OD_F32) return rocket_host_impl<float>(h, project, x, u, y, dx, du, uproj, status);
   return rocket_host_impl<double>(h, project, x, u, y, dx, du, uproj, status);
 }
@@ -2115,6 +2192,7 @@ template <class T> static int soc_project_host_impl(od_handle h, const double* u
 
 int od_soc_project_host(od_handle h, const double* u, double* uproj, double* duproj, int* status) {
   if (!h || !u) return fail(OD_ERR_INVALID, "od_soc_project_host: null argument");
+  OD_ON_DEVICE(h);
   if (h->dtype == OD_F32) return soc_project_host_impl<float>(h, u, uproj, duproj, status);
   return soc_project_host_impl<double>(h, u, uproj, duproj, status);
 }
@@ -2124,6 +2202,7 @@ int od_soc_project_host(od_handle h, const double* u, double* uproj, double* dup
 int od_bundle_grad_host(od_handle h, int N, const double* x, const double* u, const double* eta, double* dz, int* status) {
   if (int rc = check_mech(h, "od_bundle_grad_host")) return rc;
   if (!x || !eta || !dz || N <= 0 || (h->vt->nu > 0 && !u)) return fail(OD_ERR_INVALID, "od_bundle_grad_host: null argument");
+  OD_ON_DEVICE(h);
   const int nq = h->vt->nq, n = 2 * nq, nu = h->vt->nu, nzb = n + nu;
   const size_t ws = (od_bundle_workspace_bytes(h, 1, N) + 7) / 8;
   if (int rc = ensure_stage(h, (size_t)n + nu + (size_t)nzb * N + (size_t)nq * nzb + 1 + ws)) return rc;

@@ -22,16 +22,16 @@ hipError_t launch_rocket32(const RocketArgs<float>& a, int ppw, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <class T> __global__ __launch_bounds__(OD_BLOCK) void k_soc_project(RocketArgs<T> a, LaneMap lm) {
+template <class T> __global__ __launch_bounds__(OD_BLOCK) void k_soc_project(SocProjectArgs<T> a, LaneMap lm) {
   const long b = lm.problem(blockIdx.x, threadIdx.x);
-  if (lm.active(threadIdx.x) && b < a.B) unit_soc_project<Model_rocket_projection_direct, T>(a, b);
+  if (lm.active(threadIdx.x) && b < a.a.B) unit_soc_project<Model_rocket_projection_direct, T>(a, b);
 }
-hipError_t launch_soc_project64(const RocketArgs<double>& a, int ppw, hipStream_t s) {
-  hipLaunchKernelGGL((k_soc_project<double>), od_grid(a.B, ppw), dim3(OD_BLOCK), 0, s, a, LaneMap{ppw});
+hipError_t launch_soc_project64(const SocProjectArgs<double>& a, int ppw, hipStream_t s) {
+  hipLaunchKernelGGL((k_soc_project<double>), od_grid(a.a.B, ppw), dim3(OD_BLOCK), 0, s, a, LaneMap{ppw});
   return hipGetLastError();
 }
-hipError_t launch_soc_project32(const RocketArgs<float>& a, int ppw, hipStream_t s) {
-  hipLaunchKernelGGL((k_soc_project<float>), od_grid(a.B, ppw), dim3(OD_BLOCK), 0, s, a, LaneMap{ppw});
+hipError_t launch_soc_project32(const SocProjectArgs<float>& a, int ppw, hipStream_t s) {
+  hipLaunchKernelGGL((k_soc_project<float>), od_grid(a.a.B, ppw), dim3(OD_BLOCK), 0, s, a, LaneMap{ppw});
   return hipGetLastError();
 }
 

@@ -111,6 +111,17 @@ template <class T> struct StepArgs {
   int merge_grad_status;   // 1: this is the separate grad solve of a non-fusable step: merge into status / iters[1]
 };
 
+// The linearisation inside the device-resident iLQR iteration (od_ilqr_solver.inc) runs the kernels of od_step_grad on the T*B knots of
+// the nominal trajectories: a launch-level skip flag (every trajectory has converged) and a per-trajectory predicate (only the
+// trajectories that took a step have new states) ride beside the step arguments as a kernel parameter of their own -- StepArgs is
+// also what the rollout kernels take and stays as it is.  All null for every other caller.
+struct LiveArgs {
+  const int* skip;    // non-zero = the launch does nothing
+  const int* live;    // knot k belongs to trajectory k % live_mod and is computed only if live[k % live_mod] != 0
+  long live_mod;
+  OD_HD bool dead(long k) const { return live && !live[k % live_mod]; }
+};
+
 // pass-2 output: dq3/d(q1,q2,u) scattered into the reference's dx / du layout (and/or compact dq3)
 template <class M, class T> struct StepSink {
   static constexpr bool DEFER_GRAD = false;
@@ -654,7 +665,15 @@ OD_HD void rocket_knot(const RocketArgs<T>& a, long b, const T* x, T* u, T* y) {
 
 // soc_projection / soc_projection_gradient alone (dynamics.jl:168-214): u -> uproj (3), d uproj / d u (3 x 3
 // col-major, written to `du`); x, y, dx unused.  status bits 16 / 32 as in od_rocket.
-template <class MP, class T> OD_HD void unit_soc_project(const RocketArgs<T>& a, long b) {
+// (od_soc_project_full: the whole solution z of the projection's interior-point solve -- the iterate its gradient was taken at, the two
+// tolerances of this solve being equal -- and the iterations it took: what a checker needs to recompute -rz^{-1} rtheta there)
+template <class T> struct SocProjectArgs {
+  RocketArgs<T> a;
+  View<T> z;          // 10 (optional)
+  View<int> iters;    // 1 (optional)
+};
+template <class MP, class T> OD_HD void unit_soc_project(const SocProjectArgs<T>& sa, long b) {
+  const RocketArgs<T>& a = sa.a;
   T zp[MP::NZ], thp[MP::NTH], dproj[9];
 #pragma unroll
   for (int i = 0; i < MP::NZ; ++i) zp[i] = T(MP::ZI_VAL[i]);
@@ -674,6 +693,11 @@ template <class MP, class T> OD_HD void unit_soc_project(const RocketArgs<T>& a,
 #pragma unroll
     for (int i = 0; i < 9; ++i) a.du.at(i, b) = dproj[i];
   }
+  if (sa.z.ok()) {
+#pragma unroll
+    for (int i = 0; i < MP::NZ; ++i) sa.z.at(i, b) = zp[i];
+  }
+  if (sa.iters.ok()) sa.iters.at(0, b) = itp[0];
   if (a.status.ok()) a.status.at(0, b) = (sp_ & 3) << 4;
 }
 

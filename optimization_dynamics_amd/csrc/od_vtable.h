@@ -22,9 +22,9 @@ struct ModelVT {
   long coop8_auto_max;
   int ngam, nbfr;                              // z indices of the impact / friction impulses
   std::array<int, 12> gam, bfr;
-  hipError_t (*step_state)(const StepArgs<double>&, LaunchCfg, hipStream_t);        // pass 1, independent knots
+  hipError_t (*step_state)(const StepArgs<double>&, LaunchCfg, hipStream_t, LiveArgs);   // pass 1, independent knots
   hipError_t (*rollout_state)(const RolloutArgs<double>&, LaunchCfg, hipStream_t);  // pass 1, rollouts
-  hipError_t (*grad_knots)(const StepArgs<double>&, hipStream_t);                   // pass 2 (a.B knots)
+  hipError_t (*grad_knots)(const StepArgs<double>&, hipStream_t, LiveArgs);         // pass 2 (a.B knots)
   hipError_t (*rollout_policy)(const PolicyArgs<double>&, LaunchCfg, hipStream_t);  // closed-loop rollouts
   hipError_t (*bundle)(const BundleArgs<double>&, long, LaunchCfg, hipStream_t);
   hipError_t (*step_full)(const FullArgs<double>&, int ppw, hipStream_t);           // z and dz, every row
@@ -48,8 +48,8 @@ OD_FOR_EACH_MODEL(OD_DECLARE_VT)
 
 hipError_t launch_rocket64(const RocketArgs<double>&, int ppw, hipStream_t);
 hipError_t launch_rocket32(const RocketArgs<float>&, int ppw, hipStream_t);
-hipError_t launch_soc_project64(const RocketArgs<double>&, int ppw, hipStream_t);
-hipError_t launch_soc_project32(const RocketArgs<float>&, int ppw, hipStream_t);
+hipError_t launch_soc_project64(const SocProjectArgs<double>&, int ppw, hipStream_t);
+hipError_t launch_soc_project32(const SocProjectArgs<float>&, int ppw, hipStream_t);
 hipError_t launch_rocket_rollout64(const RocketRolloutArgs<double>&, int ppw, hipStream_t);
 hipError_t launch_rocket_rollout32(const RocketRolloutArgs<float>&, int ppw, hipStream_t);
 

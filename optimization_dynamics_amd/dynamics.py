@@ -55,7 +55,8 @@ class ImplicitDynamics:
                 setattr(o, k, v)
         self.options = o
         hd = C.c_void_p()
-        self.lib.check(self.lib.cdll.od_create(self.lib.model_id(model.name), _lib.OD_F64, C.byref(o), self.h, C.byref(hd)))
+        with _lib.on_device(self.device):      # (the handle lives on the device that is current in od_create; every later call runs there)
+            self.lib.check(self.lib.cdll.od_create(self.lib.model_id(model.name), _lib.OD_F64, C.byref(o), self.h, C.byref(hd)))
         self._h = hd
         self._fric_sent = None
         self._sync_friction()

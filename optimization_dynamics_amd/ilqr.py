@@ -353,8 +353,21 @@ class ILQR:
                 reg_try[again] = torch.clamp(torch.clamp(reg_try[again], min=1e-8) * 10.0, max=1e6)
         return K, k, dV, bad
 
-    def solve_stepwise(self, x1, U0, max_iter=50, max_al_iter=1, rho_init=1.0, rho_scale=10.0, con_tol=1e-3, obj_tol=1e-6, verbose=False,
-                       reuse_forward_states=True):
+    def solve_stepwise(self, *args, **kw):
+        """`_solve_stepwise` with the thrust-cone projection's stall exit switched on for the handle while it runs, as the device-resident
+        solver does for its own launches (od_ilqr_options.proj_stall_exit; the handle's default is off, like the reference)"""
+        info = getattr(self.im, "info", None)
+        if info is not None and hasattr(info, "set_projection_stall_exit"):
+            info.set_projection_stall_exit(kw.pop("proj_stall_exit", True))
+            try:
+                return self._solve_stepwise(*args, **kw)
+            finally:
+                info.set_projection_stall_exit(False)
+        kw.pop("proj_stall_exit", None)
+        return self._solve_stepwise(*args, **kw)
+
+    def _solve_stepwise(self, x1, U0, max_iter=50, max_al_iter=1, rho_init=1.0, rho_scale=10.0, con_tol=1e-3, obj_tol=1e-6, verbose=False,
+                        reuse_forward_states=True, rho_max=1e8):
         """The iteration of `solve` composed from the separate entry points with every decision taken here, on the host: the
         checker of od_ilqr_*.  Like there, the B problems are independent solves in lockstep launches: each trajectory has its own
         regularisation schedule, penalty, convergence flag (`done`) and constraint flag (`al_done`).
@@ -448,7 +461,7 @@ class ILQR:
                     lam["lam_s"] = torch.where(upd[None, None, :], l, lam["lam_s"])
             else:
                 lam = torch.where(upd[None, :], lam + rho * obj.constraint(X), lam)
-            rho = torch.where(upd, rho * rho_scale, rho)
+            rho = torch.where(upd, torch.clamp(rho * rho_scale, max=rho_max), rho)
             reg = torch.where(upd, torch.full_like(reg, float(self.reg)), reg)
             done = torch.where(upd, torch.zeros_like(done), done)
         self.last_status = dict(done=done, al_done=al_done, rho=rho, reg=reg)
@@ -459,7 +472,8 @@ class DeviceILQR:
     """od_ilqr_* (include/od_mi355x.h): the whole iLQR iteration on the device, decisions included.  `iterate(n)` only enqueues
     kernels on the current stream (capturable in a HIP graph); `solve` is od_ilqr_solve."""
 
-    def __init__(self, ilqr: ILQR, B, max_iter=50, max_al_iter=1, rho_init=1.0, rho_scale=10.0, con_tol=1e-3, obj_tol=1e-6, history=0):
+    def __init__(self, ilqr: ILQR, B, max_iter=50, max_al_iter=1, rho_init=1.0, rho_scale=10.0, con_tol=1e-3, obj_tol=1e-6, history=0,
+                 proj_stall_exit=True, rho_max=1e8):
         import ctypes as C
         from . import _lib
         im, obj = ilqr.im, ilqr.obj
@@ -470,6 +484,8 @@ class DeviceILQR:
         o.rho_init, o.rho_scale, o.max_iter, o.max_al_iter = float(rho_init), float(rho_scale), int(max_iter), int(max_al_iter)
         o.project = 1 if getattr(im, "project", True) else 0
         o.history = int(history)
+        o.proj_stall_exit = 1 if proj_stall_exit else 0
+        o.rho_max = float(rho_max)
         self.options = o
         al = np.ascontiguousarray(ilqr.alphas.cpu().numpy(), dtype=np.float64)
         dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))

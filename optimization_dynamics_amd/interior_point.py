@@ -26,7 +26,8 @@ class InteriorPoint:
         self.options = o
         hd = C.c_void_p()
         od_dtype = _lib.OD_F64 if dtype == torch.float64 else _lib.OD_F32
-        self.lib.check(self.lib.cdll.od_create(self.lib.model_id(model_name), od_dtype, C.byref(o), 0.0, C.byref(hd)))
+        with _lib.on_device(self.device):
+            self.lib.check(self.lib.cdll.od_create(self.lib.model_id(model_name), od_dtype, C.byref(o), 0.0, C.byref(hd)))
         self._h = hd
 
     def __del__(self):

@@ -37,7 +37,8 @@ class RocketInfo:
         self.options = o
         hd = C.c_void_p()
         od_dtype = _lib.OD_F64 if dtype == torch.float64 else _lib.OD_F32
-        self.lib.check(self.lib.cdll.od_create(self.lib.model_id("rocket_dynamics"), od_dtype, C.byref(o), self.h, C.byref(hd)))
+        with _lib.on_device(self.device):
+            self.lib.check(self.lib.cdll.od_create(self.lib.model_id("rocket_dynamics"), od_dtype, C.byref(o), self.h, C.byref(hd)))
         self._h = hd
         self.lib.check(self.lib.cdll.od_set_u_max(self._h, self.u_max))
 
@@ -52,6 +53,24 @@ class RocketInfo:
     def _use_current_stream(self):
         if self.device.type == "cuda":
             self.lib.check(self.lib.cdll.od_set_stream(self._h, torch.cuda.current_stream(self.device).cuda_stream))
+
+    def set_projection_stall_exit(self, on):
+        """od_set_projection_stall_exit: off (the default) runs every iteration of a stalled thrust-cone projection like the reference"""
+        self.lib.check(self.lib.cdll.od_set_projection_stall_exit(self._h, 1 if on else 0))
+
+    def project_full(self, U, grads=True):
+        """od_soc_project_full: U (3, B) -> z (10, B) whole solution of the projection's solve, duproj (3, 3, B) or None, status, iterations"""
+        self._use_current_stream()
+        U = U.to(device=self.device, dtype=self.dtype).contiguous()
+        B = U.shape[1]
+        Z = torch.empty(10, B, dtype=self.dtype, device=self.device)
+        DP = torch.zeros(9, B, dtype=self.dtype, device=self.device) if grads else None
+        st = torch.zeros(B, dtype=torch.int32, device=self.device)
+        it = torch.zeros(B, dtype=torch.int32, device=self.device)
+        self.lib.check(self.lib.cdll.od_soc_project_full(self._h, B, _ptr(U), _ptr(Z), _ptr(DP) if grads else None, _ptr(st), _ptr(it)))
+        if grads:
+            DP = DP.view(3, 3, B).transpose(0, 1)
+        return Z, DP, st, it
 
     def solve(self, X, U, project=False, grads=True):
         """batched: X (12, B), U (3, B) -> Y (12,B), DX (12,12,B), DU (12,3,B), Uproj (3,B), status (B,)"""

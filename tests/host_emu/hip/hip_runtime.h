@@ -32,7 +32,17 @@ extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+// devices: od_emu_set_device_count(n) makes n emulated devices visible; the current device is per thread, as in HIP.  Every
+// kernel launch records the device that was current (od_emu_last_launch_device) so that the tests can see the handle's device
+// guard (od_capi.hip::OnDevice) at work; streams are plain pointers whose device the tests register (od_emu_register_stream).
+extern int od_emu_ndev;
+extern thread_local int od_emu_cur_dev;
+extern int od_emu_launch_dev;
+int od_emu_stream_device(void* s);
+inline hipError_t hipGetDeviceCount(int* n) { *n = od_emu_ndev; return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = od_emu_cur_dev; return hipSuccess; }
+inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= od_emu_ndev) return 101; od_emu_cur_dev = d; return hipSuccess; }
+inline hipError_t hipStreamGetDevice(void* s, int* d) { *d = od_emu_stream_device(s); return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return hipSuccess; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 enum { hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000 };
@@ -97,6 +107,7 @@ inline uint64_t od_emu_row_ror_bits(uint64_t v, int R) {
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                 \
   do {                                                                              \
     dim3 g_ = (grid), b_ = (block);                                                 \
+    od_emu_launch_dev = od_emu_cur_dev;                                             \
     gridDim = g_; blockDim = b_;                                                    \
     if (od_emu_lockstep) {                                                          \
       for (long bx_ = 0; bx_ < (long)g_.x; ++bx_) {                                 \

@@ -1,0 +1,134 @@
+"""A handle belongs to the HIP device that was current in od_create, and every entry point runs there whatever the calling
+thread's current device is (include/od_mi355x.h "Devices"; csrc/od_capi.hip::OnDevice).  CPU tier: the host build of the product
+sources against the emulated HIP runtime (tests/host_emu), which keeps a per-thread current device, records the device every
+kernel launch saw and lets a test declare which device a stream belongs to.  GPU tier: what one visible device allows -- the
+handle reports its device, a foreign stream is refused only when it is foreign."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import parity_checks as P
+import workloads as W
+
+
+@pytest.fixture()
+def two_devices(emu_lib):
+    cd = C.CDLL(emu_lib.path)
+    cd.od_emu_set_device_count(2)
+    cd.od_emu_set_device(0)
+    yield cd
+    cd.od_emu_set_device(0)
+    cd.od_emu_set_device_count(1)
+
+
+def test_entry_points_run_on_the_device_of_their_handle(emu_lib, two_devices):
+    emu = two_devices
+    emu.od_emu_set_device(1)
+    im = P.make_im("hopper", emu_lib, "cpu")                 # od_create under current device 1
+    dev = C.c_int(-1)
+    emu_lib.check(emu_lib.cdll.od_get_device(im._h, C.byref(dev)))
+    assert dev.value == 1
+    X, U = W.knots("hopper", 8, seed=3)
+    ref = [t.clone() for t in im.step_grad(torch.tensor(X), torch.tensor(U))]
+    assert emu.od_emu_last_launch_device() == 1
+    # the caller moves on to device 0: the handle's launches still happen on device 1, and the caller's device is put back
+    emu.od_emu_set_device(0)
+    got = im.step_grad(torch.tensor(X), torch.tensor(U))
+    assert emu.od_emu_last_launch_device() == 1, "the launch ran on the caller's current device, not on the handle's"
+    assert emu.od_emu_get_device() == 0, "the caller's current device was not restored"
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    # ... for rollouts, the host-vector callbacks and the device-resident solver alike
+    x1, Ur = W.hopper_rollout_inputs(4, 3, seed=1)
+    im.rollout(torch.tensor(x1), torch.tensor(Ur))
+    assert emu.od_emu_last_launch_device() == 1 and emu.od_emu_get_device() == 0
+    d = np.zeros(8)
+    from optimization_dynamics_amd import dynamics as dyn
+    dyn.f(d, im, X[:, 0], U[:, 0], None)
+    assert emu.od_emu_last_launch_device() == 1 and emu.od_emu_get_device() == 0
+    al = (C.c_double * 2)(1.0, 0.5)
+    s = C.c_void_p()
+    emu_lib.check(emu_lib.cdll.od_ilqr_create(im._h, 4, 3, 2, al, None, C.byref(s)))
+    assert emu.od_emu_get_device() == 0
+    assert emu_lib.cdll.od_ilqr_destroy(s) == 0
+    # a second handle made now lives on device 0; the two do not disturb each other
+    im0 = P.make_im("hopper", emu_lib, "cpu")
+    emu_lib.check(emu_lib.cdll.od_get_device(im0._h, C.byref(dev)))
+    assert dev.value == 0
+    im0.step(torch.tensor(X), torch.tensor(U))
+    assert emu.od_emu_last_launch_device() == 0
+    im.step(torch.tensor(X), torch.tensor(U))
+    assert emu.od_emu_last_launch_device() == 1 and emu.od_emu_get_device() == 0
+
+
+def test_stream_of_another_device_is_refused(emu_lib, two_devices):
+    emu = two_devices
+    emu.od_emu_set_device(1)
+    im = P.make_im("cartpole_friction", emu_lib, "cpu")
+    emu.od_emu_set_device(0)
+    emu.od_emu_register_stream(C.c_void_p(0x1000), 0)
+    emu.od_emu_register_stream(C.c_void_p(0x2000), 1)
+    rc = emu_lib.cdll.od_set_stream(im._h, C.c_void_p(0x1000))
+    assert rc == -5 and b"device 0" in emu_lib.cdll.od_last_error()          # OD_ERR_WRONG_DEVICE
+    assert emu_lib.cdll.od_set_stream(im._h, C.c_void_p(0x2000)) == 0
+    assert emu_lib.cdll.od_set_stream(im._h, None) == 0
+    assert emu.od_emu_get_device() == 0
+
+
+def test_destroying_the_handle_before_its_solver_is_safe(emu_lib):
+    """a garbage collector gives no order between the two finalisers (julia/OptimizationDynamicsMI355X.jl, ILQRSolver): od_destroy
+    releases what its live solvers hold and detaches them; the solver object then answers with an error code and can still be
+    destroyed"""
+    from optimization_dynamics_amd import _lib
+    cd = emu_lib.cdll
+    h = C.c_void_p()
+    o = emu_lib.default_options("cartpole_friction")
+    emu_lib.check(cd.od_create(emu_lib.model_id("cartpole_friction"), _lib.OD_F64, C.byref(o), 0.05, C.byref(h)))
+    al = (C.c_double * 2)(1.0, 0.5)
+    s1, s2 = C.c_void_p(), C.c_void_p()
+    emu_lib.check(cd.od_ilqr_create(h, 4, 3, 2, al, None, C.byref(s1)))
+    emu_lib.check(cd.od_ilqr_create(h, 2, 5, 2, al, None, C.byref(s2)))
+    assert cd.od_ilqr_destroy(s1) == 0                       # the usual order for one of them
+    assert cd.od_destroy(h) == 0                             # ... and the handle before the other
+    info = _lib.IlqrInfo()
+    assert cd.od_ilqr_get_info(s2, C.byref(info)) == -1 and b"destroyed" in cd.od_last_error()
+    assert cd.od_ilqr_iterate(s2, 1) == -1
+    assert cd.od_ilqr_destroy(s2) == 0
+
+
+def test_constraints_can_be_replaced_without_growth(emu_lib):
+    """od_ilqr_set_constraints allocates its buffers once: replacing the constraints many times reuses them, and what is in force
+    after each call is what that call passed"""
+    cd = emu_lib.cdll
+    im = P.make_im("cartpole_friction", emu_lib, "cpu")
+    al = (C.c_double * 2)(1.0, 0.5)
+    s = C.c_void_p()
+    emu_lib.check(cd.od_ilqr_create(im._h, 3, 4, 2, al, None, C.byref(s)))
+    dp = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))
+    Q = np.eye(4); R = np.eye(1)
+    emu_lib.check(cd.od_ilqr_set_objective(s, dp(Q), dp(R), dp(Q), dp(np.zeros(4)), 0, None, None))
+    for k in range(40):
+        ns = 1 + k % 3
+        Cs = np.zeros((ns, 4)); Ds = np.ones((ns, 1)); ds = np.full(ns, 2.0 + k)
+        emu_lib.check(cd.od_ilqr_set_constraints(s, ns, ns, dp(Cs.T.copy()), dp(Ds.T.copy()), dp(ds), 1, 0, dp(np.array([[1.0, 0, 0, 0]]).T.copy()), dp(np.array([0.5]))))
+    x1 = torch.zeros(4, 3, dtype=torch.float64); U0 = torch.full((1, 4, 3), 0.1, dtype=torch.float64)
+    emu_lib.check(cd.od_ilqr_init(s, x1.data_ptr(), U0.data_ptr()))
+    emu_lib.check(cd.od_ilqr_set_constraints(s, 0, 0, None, None, None, 0, 0, None, None))
+    assert cd.od_ilqr_destroy(s) == 0
+
+
+@pytest.mark.gpu
+def test_handle_reports_its_device_gpu(gpu_lib):
+    im = P.make_im("hopper", gpu_lib, "cuda:0")
+    dev = C.c_int(-1)
+    gpu_lib.check(gpu_lib.cdll.od_get_device(im._h, C.byref(dev)))
+    assert dev.value == torch.cuda.current_device() == 0
+    s = torch.cuda.Stream(device="cuda:0")
+    assert gpu_lib.cdll.od_set_stream(im._h, C.c_void_p(s.cuda_stream)) == 0          # a stream of the handle's own device
+    X, U = W.knots("hopper", 64, seed=3)
+    with torch.cuda.stream(s):
+        D, st, it = im.step(torch.tensor(X), torch.tensor(U))
+    s.synchronize()
+    assert ((st & 1) == 1).double().mean().item() > 0.95

@@ -182,3 +182,52 @@ def test_workload_slices_are_consistent():
         assert np.array_equal(b, a[:, lo:hi]) and np.array_equal(ub, ua[:, :, lo:hi])
     x1, U = bench.make_inputs(16, 4, seed=2)
     assert np.array_equal(a[:, 32:48], x1)
+
+
+def test_bench_force_dist_runs_the_multi_rank_path_with_one_rank(emu_lib, tmp_path):
+    """`bench.py --force-dist --gather`: ONE rank under torch.distributed.run, process group initialised, barriers, max-over-ranks
+    all-reduce and all_gather_into_tensor all executed (gloo + host build here; the -m gpu twin below runs the same lines over
+    RCCL on the MI355X) -- and the gathered result is the plain rollout"""
+    dump = str(tmp_path / "forced.npz")
+    rec = _run_bench(emu_lib, ["--force-dist", "--gather", "--test-dump", dump])
+    assert rec["n_gpus"] == 1 and rec["ranks_seen"] == 1 and rec["backend"] == "gloo"
+    assert "all-gather" in rec["config"]["parallelism"] and rec["value"] > 0
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench
+    import parity_checks as P
+    x1, U = bench.workload_slice(0, 16, 16, 6)
+    X, G, st, it, _ = P.make_im("hopper", emu_lib, "cpu").rollout_compact(torch.tensor(x1), torch.tensor(U))
+    g = np.load(dump)
+    assert np.array_equal(g["X"], X.numpy()) and np.array_equal(g["G"], G.numpy())
+
+
+@pytest.mark.gpu
+def test_bench_force_dist_over_rccl_gpu(tmp_path):
+    """the multi-rank path of bench.py on the hardware: torch.distributed.run --nproc-per-node 1, backend nccl (= RCCL), --gather --
+    init_process_group, barrier, all_reduce(MAX) and all_gather_into_tensor on device tensors; the record says so, and the
+    gathered linearisation equals the single-process rollout bit for bit"""
+    import json
+    import subprocess
+    dump = str(tmp_path / "rccl.npz")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--gather", "--steps", "3", "--warmup", "1", "--batch", "256",
+           "--horizon", "10", "--no-cpu-baseline", "--test-dump", dump]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["ranks_seen"] == 1 and rec["backend"] == "nccl", rec
+    assert "all-gather" in rec["config"]["parallelism"] and rec["value"] > 0
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    json.dump(rec, open(os.path.join(d, "force_dist_rccl.json"), "w"), indent=1)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench
+    import parity_checks as P
+    from optimization_dynamics_amd import _lib
+    x1, U = bench.workload_slice(0, 256, 256, 10)
+    X, G, st, it, _ = P.make_im("hopper", _lib.default_library(), "cuda:0").rollout_compact(torch.tensor(x1), torch.tensor(U))
+    g = np.load(dump)
+    assert np.array_equal(g["X"], X.cpu().numpy()) and np.array_equal(g["G"], G.cpu().numpy())

@@ -74,11 +74,11 @@ def test_struct_mirrors_match_the_header_field_for_field():
         assert jf == [(n, jtype[ty]) for ty, n in fields], (jname, jf)
 
 
-def test_implicit_dynamics_callbacks_sequence(oracle, emu_lib):
+def _implicit_dynamics_callbacks_sequence(oracle, emu_lib, device):
     """f / fx / fu / ffxfu! (od_f_host, od_fx_host, od_fu_host, od_ffxfu_host) incl. the friction re-sync before each"""
     name = "cartpole_friction"
     X, U = W.knots(name, 3, seed=51)
-    im = P.make_im(name, emu_lib, "cpu")
+    im = P.make_im(name, emu_lib, device)
     h = im._h
     mu = np.array([0.35, 0.35])
     n, nu = 4, 1
@@ -102,13 +102,13 @@ def test_implicit_dynamics_callbacks_sequence(oracle, emu_lib):
     assert emu_lib.cdll.od_ffxfu_host(h, _p(x), _p(u), _p(d3), None, None) == 0 and np.array_equal(d3, d2)
 
 
-def test_gradient_bundle_sequence(oracle, emu_lib):
+def _gradient_bundle_sequence(oracle, emu_lib, device):
     """gradient! / fx_gb / fu_gb: od_bundle_grad_host(h, N, x, u, eta, dz, NULL)"""
     from optimization_dynamics_amd import gradient_bundle as gbm, models
     name = "hopper"
     X, U = W.knots(name, 2, seed=31)
     gb = gbm.GradientBundle(models.BY_NAME[name], N=50, eps=1e-4, seed=5)
-    im = P.make_im(name, emu_lib, "cpu", info=gb)
+    im = P.make_im(name, emu_lib, device, info=gb)
     nq, nzb = 4, 10
     dzb, st = gbm.gradient_batch(im, gb, torch.tensor(X), torch.tensor(U))
     for b in range(2):
@@ -116,10 +116,10 @@ def test_gradient_bundle_sequence(oracle, emu_lib):
         dz = np.zeros((nq, nzb), order="F")
         eta = np.asfortranarray(gb.eta)
         assert emu_lib.cdll.od_bundle_grad_host(im._h, 50, _p(x), _p(u), _p(eta), _p(dz), None) == 0
-        assert np.array_equal(dz, dzb[:, :, b].numpy())
+        assert np.array_equal(dz, dzb[:, :, b].cpu().numpy())
 
 
-def test_rocket_sequence(oracle, emu_lib):
+def _rocket_sequence(oracle, emu_lib, device):
     """RocketInfo: od_create(rocket, NULL opts) + od_set_u_max; f/fx/fu_rocket(_proj) = od_rocket_host with NULLs;
     soc_projection(_gradient) = od_soc_project_host"""
     from optimization_dynamics_amd import models, rocket as rk
@@ -127,7 +127,7 @@ def test_rocket_sequence(oracle, emu_lib):
     assert emu_lib.cdll.od_create(5, 0, None, C.c_double(0.05), C.byref(hd)) == 0
     assert emu_lib.cdll.od_set_u_max(hd, C.c_double(12.5)) == 0
     Xr, Ur = W.rocket_inputs(3, seed=1)
-    info = rk.RocketInfo(models.rocket, 12.5, 0.05, device="cpu", lib=emu_lib)
+    info = rk.RocketInfo(models.rocket, 12.5, 0.05, device=device, lib=emu_lib)
     for project in (0, 1):
         Yb, DXb, DUb, UPb, stb = info.solve(torch.tensor(Xr), torch.tensor(Ur), project=bool(project), grads=True)
         for b in range(3):
@@ -136,7 +136,7 @@ def test_rocket_sequence(oracle, emu_lib):
             assert emu_lib.cdll.od_rocket_host(hd, project, _p(x), _p(u), _p(y), None, None, None, None) == 0       # f_rocket(_proj)
             assert emu_lib.cdll.od_rocket_host(hd, project, _p(x), _p(u), None, _p(dx), None, None, None) == 0      # fx_rocket(_proj)
             assert emu_lib.cdll.od_rocket_host(hd, project, _p(x), _p(u), None, None, _p(du), None, None) == 0      # fu_rocket(_proj)
-            assert np.array_equal(y, Yb[:, b].numpy()) and np.array_equal(dx, DXb[:, :, b].numpy()) and np.array_equal(du, DUb[:, :, b].numpy())
+            assert np.array_equal(y, Yb[:, b].cpu().numpy()) and np.array_equal(dx, DXb[:, :, b].cpu().numpy()) and np.array_equal(du, DUb[:, :, b].cpu().numpy())
     up = np.zeros(3); dp = np.zeros((3, 3), order="F")
     u = np.ascontiguousarray(Ur[:, 0])
     assert emu_lib.cdll.od_soc_project_host(hd, _p(u), _p(up), None, None) == 0
@@ -147,6 +147,36 @@ def test_rocket_sequence(oracle, emu_lib):
     assert np.abs(up - z[:3]).max() < 2e-4 * max(1, np.abs(z[:3]).max())
     assert np.hypot(up[0], up[1]) <= up[2] + 2e-2            # examples/rocket.jl:151
     assert emu_lib.cdll.od_destroy(hd) == 0
+
+
+
+# the three call sequences on the host build of the product sources (CPU tier) and on the shipped HIP library (-m gpu): the shim's
+# *_host entry points are the boundary of BASELINE config 1
+def test_implicit_dynamics_callbacks_sequence(oracle, emu_lib):
+    _implicit_dynamics_callbacks_sequence(oracle, emu_lib, "cpu")
+
+
+def test_gradient_bundle_sequence(oracle, emu_lib):
+    _gradient_bundle_sequence(oracle, emu_lib, "cpu")
+
+
+def test_rocket_sequence(oracle, emu_lib):
+    _rocket_sequence(oracle, emu_lib, "cpu")
+
+
+@pytest.mark.gpu
+def test_implicit_dynamics_callbacks_sequence_gpu(oracle, gpu_lib):
+    _implicit_dynamics_callbacks_sequence(oracle, gpu_lib, "cuda:0")
+
+
+@pytest.mark.gpu
+def test_gradient_bundle_sequence_gpu(oracle, gpu_lib):
+    _gradient_bundle_sequence(oracle, gpu_lib, "cuda:0")
+
+
+@pytest.mark.gpu
+def test_rocket_sequence_gpu(oracle, gpu_lib):
+    _rocket_sequence(oracle, gpu_lib, "cuda:0")
 
 
 def test_rocket_host_entry_points_on_a_single_precision_handle(emu_lib):
