@@ -274,3 +274,28 @@ int od_arbiter_soc_projection(double u_max, const double* u, int exact_acceptanc
   if (lin_err) *lin_err = lerr;
   return (r_vio < (q128)o->r_tol && k_vio < kappa_tol) ? 1 : 0;
 }
+
+/* batched (OpenMP) forms.  od_arbiter_gradient_batch: Z nz x B, TH nth x B, reg B (NULL = 0) -> DZ (nz*nth) x B, cond B.
+ * od_arbiter_soc_projection_batch: U 3 x B -> Z 10 x B, ok / iters B. */
+int od_arbiter_gradient_batch(int model_id, int B, const double* Z, const double* TH, const double* reg, double* DZ, double* cond) {
+  const od_oracle_model* m = od_oracle_models[model_id];
+  const int nz = m->nz, nth = m->nth;
+  int bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(dynamic, 16)
+  for (int b = 0; b < B; ++b)
+    bad += !od_arbiter_gradient(model_id, Z + (size_t)nz * b, TH + (size_t)nth * b, reg ? reg[b] : 0.0, DZ + (size_t)nz * nth * b, cond ? cond + b : NULL);
+  return bad;
+}
+int od_arbiter_soc_projection_batch(double u_max, int B, const double* U, int exact_acceptance, double* Z, int* ok, int* iters) {
+  int bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(dynamic, 8)
+  for (int b = 0; b < B; ++b) {
+    int it = 0;
+    double le;
+    const int o = od_arbiter_soc_projection(u_max, U + 3 * (size_t)b, exact_acceptance, Z + 10 * (size_t)b, &it, NULL, &le);
+    if (ok) ok[b] = o;
+    if (iters) iters[b] = it;
+    bad += !o;
+  }
+  return bad;
+}

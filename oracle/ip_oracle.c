@@ -588,4 +588,90 @@ int od_oracle_rollout(const od_oracle_sim* s, int B, int T, const double* x1, co
   return bad;
 }
 
+/* ----------------------------------------------------------------------------------------------
+ * batched (OpenMP) forms of the rocket functions for the parity sweeps (tests/test_gpu_parity_sweep.py, tests/ilqr_checks.py):
+ * col-major arrays with the knot index last, like od_oracle_step_grad_batch
+ * -------------------------------------------------------------------------------------------- */
+/* f_rocket + (diff_sol) fx / fu_rocket on B knots: X 12 x B, U 3 x B -> Y 12 x B, DZ (12*16) x B (may be NULL), status / iters B */
+int od_oracle_rocket_batch(double h, int B, const double* X, const double* U, int diff_sol, double* Y, double* DZ, int* status, int* iters) {
+  int bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(dynamic, 32)
+  for (int b = 0; b < B; ++b) {
+    int it = 0;
+    double dz[12 * 16];
+    const int ok = od_oracle_rocket(h, X + 12 * (size_t)b, U + 3 * (size_t)b, diff_sol, Y + 12 * (size_t)b, (diff_sol && DZ) ? DZ + 192 * (size_t)b : dz, &it);
+    if (status) status[b] = ok;
+    if (iters) iters[b] = it;
+    bad += !ok;
+  }
+  return bad;
+}
+/* soc_projection(_gradient) on B controls: U 3 x B -> Z 10 x B, DZ 40 x B (may be NULL), status / iters B */
+int od_oracle_soc_projection_batch(double u_max, int B, const double* U, int diff_sol, double* Z, double* DZ, int* status, int* iters) {
+  int bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(dynamic, 32)
+  for (int b = 0; b < B; ++b) {
+    int it = 0;
+    double dz[40];
+    const int ok = od_oracle_soc_projection(u_max, U + 3 * (size_t)b, diff_sol, Z + 10 * (size_t)b, (diff_sol && DZ) ? DZ + 40 * (size_t)b : dz, &it);
+    if (status) status[b] = ok;
+    if (iters) iters[b] = it;
+    bad += !ok;
+  }
+  return bad;
+}
+/* iLQR.rollout over f_rocket (project = 0) or f_rocket_proj (project = 1), examples/rocket.jl:29-41,118: B trajectories of T steps,
+ * open loop (K = NULL) or closed loop u = ubar + alpha kff + K (x - xbar) (xbar 12 x (T+1) x B, K (3*12) x T x B col-major per knot,
+ * kff 3 x T x B).  x1 12 x B, Ubar 3 x T x B -> X 12 x (T+1) x B, Uapp 3 x T x B (controls before projection; may be NULL),
+ * status T x B (bit 0 dynamics, bit 4 projection converged; may be NULL) */
+int od_oracle_rocket_rollout(double h, double u_max, int project, int B, int T, const double* x1, const double* Ubar, double alpha,
+                             const double* xbar, const double* K, const double* kff, double* X, double* Uapp, int* status) {
+  int bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(dynamic, 1)
+  for (int b = 0; b < B; ++b) {
+    double* Xb = X + (size_t)12 * (T + 1) * b;
+    memcpy(Xb, x1 + 12 * (size_t)b, 12 * sizeof(double));
+    for (int t = 0; t < T; ++t) {
+      const size_t kn = (size_t)t + (size_t)T * b;
+      double u[3], up[3], zp[10], dzp[40];
+      int it, st = 0;
+      for (int j = 0; j < 3; ++j) u[j] = Ubar[3 * kn + j];
+      if (K) {
+        const double* xb = xbar + 12 * ((size_t)t + (size_t)(T + 1) * b);
+        for (int j = 0; j < 3; ++j) u[j] += alpha * kff[3 * kn + j];
+        for (int i = 0; i < 12; ++i) {
+          const double dxi = Xb[12 * t + i] - xb[i];
+          for (int j = 0; j < 3; ++j) u[j] += K[36 * kn + j + 3 * i] * dxi;
+        }
+      }
+      if (Uapp) for (int j = 0; j < 3; ++j) Uapp[3 * kn + j] = u[j];
+      if (project) {
+        const int okp = od_oracle_soc_projection(u_max, u, 0, zp, dzp, &it);
+        st |= okp << 4;
+        up[0] = zp[0]; up[1] = zp[1]; up[2] = zp[2];
+      } else { up[0] = u[0]; up[1] = u[1]; up[2] = u[2]; st |= 1 << 4; }
+      double dz[192];
+      const int okd = od_oracle_rocket(h, Xb + 12 * t, up, 0, Xb + 12 * (t + 1), dz, &it);
+      st |= okd;
+      if (status) status[kn] = st;
+      bad += (st != 0x11);
+    }
+  }
+  return bad;
+}
+
+/* residual_violation / bilinear_violation of B given points (the convergence test of interior_point_solve!, SURVEY.md 3.4, at kappa = 0):
+ * Z nz x B, TH nth x B -> r_vio, k_vio (B each).  Lets a test verify that an end point some other implementation returned passes the
+ * algorithm's own stopping rule. */
+void od_oracle_violations_batch(int model_id, int B, const double* Z, const double* TH, double* r_vio, double* k_vio) {
+  const od_oracle_model* m = od_oracle_models[model_id];
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < B; ++b) {
+    double r[NZMAX];
+    m->r(Z + (size_t)m->nz * b, TH + (size_t)m->nth * b, 0.0, r);
+    r_vio[b] = residual_violation(m, r);
+    k_vio[b] = bilinear_violation(m, r);
+  }
+}
+
 #include "arbiter.c"

@@ -325,3 +325,83 @@ def project_thrust_cone(u, u_max):
     _, r, tt = min(cands)
     s = r / a if a > 0 else 0.0
     return np.array([u[0] * s, u[1] * s, tt])
+
+
+# ---- batched (OpenMP) rocket functions: the parity sweeps (tests/test_gpu_parity_sweep.py, tests/ilqr_checks.py) ----------------
+def _pi(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int)) if a is not None else None
+
+
+def rocket_batch(h, X, U, diff_sol=True):
+    """f_rocket (+ fx / fu_rocket) on B knots: X (12, B), U (3, B) -> Y (12, B), DZ (12, 16, B) or None, status (B,), iters (B,)"""
+    X = np.asfortranarray(X, dtype=np.float64); U = np.asfortranarray(U, dtype=np.float64)
+    B = X.shape[1]
+    Y = np.zeros(12 * B); DZ = np.zeros(192 * B) if diff_sol else None
+    st = np.zeros(B, dtype=np.int32); it = np.zeros(B, dtype=np.int32)
+    lib().od_oracle_rocket_batch(C.c_double(h), B, _p(X.reshape(-1, order="F")), _p(U.reshape(-1, order="F")), int(diff_sol), _p(Y), _p(DZ), _pi(st), _pi(it))
+    return Y.reshape(12, B, order="F"), (DZ.reshape(12, 16, B, order="F") if diff_sol else None), st, it
+
+
+def soc_projection_batch(u_max, U, diff_sol=True):
+    """soc_projection(_gradient) on B controls: U (3, B) -> Z (10, B), DZ (10, 4, B) or None, status (B,), iters (B,)"""
+    U = np.asfortranarray(U, dtype=np.float64)
+    B = U.shape[1]
+    Z = np.zeros(10 * B); DZ = np.zeros(40 * B) if diff_sol else None
+    st = np.zeros(B, dtype=np.int32); it = np.zeros(B, dtype=np.int32)
+    lib().od_oracle_soc_projection_batch(C.c_double(u_max), B, _p(U.reshape(-1, order="F")), int(diff_sol), _p(Z), _p(DZ), _pi(st), _pi(it))
+    return Z.reshape(10, B, order="F"), (DZ.reshape(10, 4, B, order="F") if diff_sol else None), st, it
+
+
+def rocket_rollout(h, u_max, x1, Ubar, project=True, policy=None):
+    """iLQR.rollout over f_rocket(_proj) (examples/rocket.jl:29-41,118): x1 (12, B), Ubar (3, T, B); policy = (alpha, xbar (12, T+1, B),
+    K (3, 12, T, B), kff (3, T, B)) for the closed loop u = ubar + alpha kff + K (x - xbar).
+    -> X (12, T+1, B), U applied (before projection) (3, T, B), status (T, B) (bit 0 dynamics, bit 4 projection converged)"""
+    x1 = np.asfortranarray(x1, dtype=np.float64); Ubar = np.asfortranarray(Ubar, dtype=np.float64)
+    T, B = Ubar.shape[1], Ubar.shape[2]
+    X = np.zeros(12 * (T + 1) * B); Ua = np.zeros(3 * T * B); st = np.zeros(T * B, dtype=np.int32)
+    if policy is None:
+        alpha, xb, K, kf = 0.0, None, None, None
+    else:
+        alpha = float(policy[0])
+        xb = np.asfortranarray(policy[1], dtype=np.float64).reshape(-1, order="F")
+        K = np.asfortranarray(policy[2], dtype=np.float64).reshape(-1, order="F")          # (3, 12, T, B): element j + 3 i of knot (t, b)
+        kf = np.asfortranarray(policy[3], dtype=np.float64).reshape(-1, order="F")
+    lib().od_oracle_rocket_rollout(C.c_double(h), C.c_double(u_max), int(bool(project)), B, T, _p(x1.reshape(-1, order="F")), _p(Ubar.reshape(-1, order="F")),
+                                   C.c_double(alpha), _p(xb), _p(K), _p(kf), _p(X), _p(Ua), _pi(st))
+    return X.reshape(12, T + 1, B, order="F"), Ua.reshape(3, T, B, order="F"), st.reshape(T, B, order="F")
+
+
+def arbiter_gradient_batch(model, Z, TH, reg=None):
+    """EXTENDED-PRECISION ARBITER, batched: dz/dtheta = -rz(z; reg)^{-1} rtheta(z) in binary128 at the given iterates.
+    Z (nz, B), TH (nth, B), reg (B,) or None -> DZ (nz, nth, B), cond (B,)"""
+    d = dims(model)
+    nz, nth = d["nz"], d["nth"]
+    Z = np.asfortranarray(Z, dtype=np.float64); TH = np.asfortranarray(TH, dtype=np.float64)
+    B = Z.shape[1]
+    DZ = np.zeros(nz * nth * B); cond = np.zeros(B)
+    r = None if reg is None else np.ascontiguousarray(reg, dtype=np.float64)
+    lib().od_arbiter_gradient_batch(MODEL_IDS[model] if isinstance(model, str) else model, B, _p(Z.reshape(-1, order="F")), _p(TH.reshape(-1, order="F")), _p(r), _p(DZ), _p(cond))
+    return DZ.reshape(nz, nth, B, order="F"), cond
+
+
+def arbiter_soc_projection_batch(u_max, U, exact_acceptance=True):
+    """the thrust-cone projection in binary128 on B controls (arbiter_soc_projection): U (3, B) -> Z (10, B), ok (B,), iters (B,)"""
+    U = np.asfortranarray(U, dtype=np.float64)
+    B = U.shape[1]
+    Z = np.zeros(10 * B); ok = np.zeros(B, dtype=np.int32); it = np.zeros(B, dtype=np.int32)
+    lib().od_arbiter_soc_projection_batch(C.c_double(u_max), B, _p(U.reshape(-1, order="F")), int(bool(exact_acceptance)), _p(Z), _pi(ok), _pi(it))
+    return Z.reshape(10, B, order="F"), ok, it
+
+
+def project_thrust_cone_batch(U, u_max):
+    return np.stack([project_thrust_cone(U[:, b], u_max) for b in range(U.shape[1])], axis=1)
+
+
+def violations_batch(model, Z, TH):
+    """the stopping test of the interior-point loop at given points: -> r_vio (B,), k_vio (B,) (max |equality rows|, max |bilinear rows| at kappa = 0)"""
+    d = dims(model)
+    Z = np.asfortranarray(Z, dtype=np.float64); TH = np.asfortranarray(TH, dtype=np.float64)
+    B = Z.shape[1]
+    rv = np.zeros(B); kv = np.zeros(B)
+    lib().od_oracle_violations_batch(MODEL_IDS[model] if isinstance(model, str) else model, B, _p(Z.reshape(-1, order="F")), _p(TH.reshape(-1, order="F")), _p(rv), _p(kv))
+    return rv, kv

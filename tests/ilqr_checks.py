@@ -239,36 +239,44 @@ def rocket_problem(lib, device, B, T, dtype=torch.float64, seed=0):
     return dyn, obj, x1, U0
 
 
-def check_rollout_against_oracle(oracle, dyn, x1, U0, X, A, Bm, dtype, ntraj=2, h=0.05, u_max=12.5):
-    """a projected rocket rollout of the device (X, and its linearisation A, Bm) against the oracle, in the handle's precision:
+def check_rollout_against_oracle(oracle, dyn, x1, U0, X, A, Bm, dtype, ntraj=64, h=0.05, u_max=12.5):
+    """a projected rocket rollout of the device (X, and its linearisation A, Bm) against the oracle on the first `ntraj` trajectories
+    (the oracle's rollouts and solves run batched under OpenMP), in the handle's precision:
       * chained: the oracle's f_rocket_proj from x1 along the same controls -- the projected control is only kappa_tol = 1e-4
-        accurate by construction and its line search has rounding-level ties (parity_checks.check_rocket), so chained states
+        accurate by construction and its line search has rounding-level ties (parity_checks.check_rocket_sweep), so chained states
         agree to that level (1e-3) in either precision;
       * knot by knot, no path dependence left: f_rocket_proj / fx of the device on its own rollout states (independent knots, the
         solve the linearisation comes from) against the oracle's dynamics step from the same state with the control the DEVICE
-        projected to -- at the bars (1e-6 / 1e-4 double, 5e-4 / 2e-2 single)"""
+        projected to -- at the north_star's bars in both precisions (1e-6 / 1e-4: the single-precision handle finishes its dynamics
+        steps in double, od_set_mixed_precision), on every converged knot of those trajectories"""
     T = U0.shape[1]
-    tolS, tolG = (1e-6, 1e-4) if dtype == torch.float64 else (5e-4, 2e-2)
-    Xn, An = X.double().cpu().numpy(), A.double().cpu().numpy()
-    for b in range(ntraj):
-        x = x1[:, b].copy()
-        for t in range(T):
-            ok, x, dx, du = oracle.rocket_proj(h, u_max, x, U0[:, t, b])
-            assert np.abs(Xn[:, t + 1, b] - x).max() < 1e-3 * max(1, np.abs(x).max()), (b, t)
-        assert np.abs(An[:, :, T - 1, b] - dx).max() < 2e-2 * max(1, np.abs(dx).max())
-        Xk, Uk = torch.tensor(Xn[:, :T, b]), torch.tensor(U0[:, :, b])
-        Y, DX, DU, UP, st = dyn.info.solve(Xk, Uk, project=True, grads=True)
-        Y, DX, UP, st = Y.double().cpu().numpy(), DX.double().cpu().numpy(), UP.double().cpu().numpy(), st.cpu().numpy()
-        for t in range(T):
-            if (st[t] & 0x33) != 0x33:
-                continue
-            # (the rollout kernel and the independent-knot kernel are two compilations of the same solve: where their projections take
-            # different line-search paths they differ at the projection's kappa_tol level, like device and oracle do)
-            assert np.abs(Y[:, t] - Xn[:, t + 1, b]).max() <= 1e-3 * max(1, np.abs(Y[:, t]).max()), (b, t)
-            ok, y, dz, it = oracle.rocket(h, Xn[:, t, b], UP[:, t], True)
-            assert np.abs(Y[:, t] - y).max() < tolS * max(1, np.abs(y).max()), (b, t, np.abs(Y[:, t] - y).max())
-            assert np.abs(DX[:, :, t] - dz[:, :12]).max() < tolG * max(1, np.abs(dz[:, :12]).max()), (b, t)
-            assert np.abs(DX[:, :, t] - An[:, :, t, b]).max() <= 1e-6 * max(1, np.abs(DX[:, :, t]).max())      # the linearisation IS that solve
+    nt = min(ntraj, x1.shape[1])
+    Uq = U0.astype(np.float32).astype(np.float64) if dtype == torch.float32 else U0
+    Xn, An = X.double().cpu().numpy()[:, :, :nt], A.double().cpu().numpy()[:, :, :, :nt]
+    Xo, _, so = oracle.rocket_rollout(h, u_max, x1[:, :nt], Uq[:, :, :nt], project=True)
+    okt = (so == 0x11).all(0)                                   # trajectories whose every oracle solve converged
+    assert okt.mean() > 0.9
+    err = np.abs(Xn - Xo).max(0) / np.maximum(1.0, np.abs(Xo).max(0))          # (T+1, nt)
+    assert err[:, okt].max() < 1e-3, float(err[:, okt].max())
+    # independent knots: the device's own states, all T * nt of them in one launch
+    Xk = np.ascontiguousarray(Xn[:, :T].reshape(12, T * nt))
+    Uk = np.ascontiguousarray(Uq[:, :, :nt].reshape(3, T * nt))
+    Y, DX, DU, UP, st = dyn.info.solve(torch.tensor(Xk), torch.tensor(Uk), project=True, grads=True)
+    Y, DX, UP, st = Y.double().cpu().numpy(), DX.double().cpu().numpy(), UP.double().cpu().numpy(), st.cpu().numpy()
+    Yo, DZo, sto, _ = oracle.rocket_batch(h, Xk, UP, True)
+    ok = ((st & 0x33) == 0x33) & (sto == 1)
+    assert ok.mean() > 0.99, ok.mean()
+    rel = lambda a, b: np.abs(a - b).reshape(-1, T * nt).max(0) / np.maximum(1.0, np.abs(b).reshape(-1, T * nt).max(0))
+    es, ex = rel(Y, Yo)[ok], rel(DX, DZo[:, :12])[ok]
+    assert es.max() < 1e-6 and ex.max() < 1e-4, (str(dtype), float(es.max()), float(ex.max()))
+    # (the rollout kernel and the independent-knot kernel are two compilations of the same solve: where their projections take
+    # different line-search paths they differ at the projection's kappa_tol level, like device and oracle do)
+    Xn1 = Xn[:, 1:].reshape(12, T * nt)
+    assert rel(Y, Xn1)[ok].max() <= 1e-3
+    # the linearisation IS that solve
+    Ak = An.reshape(12, 12, T * nt)
+    assert rel(DX, Ak)[ok].max() <= 1e-6
+    return dict(trajectories=int(nt), knots=int(ok.sum()), chained_state_rel_max=float(err[:, okt].max()), knot_state_rel_max=float(es.max()), knot_fx_rel_max=float(ex.max()))
 
 
 def check_rocket_ilqr(oracle, lib, device, B=4, T=20, dtype=torch.float64):
@@ -276,7 +284,7 @@ def check_rocket_ilqr(oracle, lib, device, B=4, T=20, dtype=torch.float64):
     x1t, Ut = torch.tensor(x1, device=device), torch.tensor(U0, device=device)
     # rollout == chained f_rocket_proj of the oracle, in either precision
     X, A, Bm, st, _, _ = dyn.rollout(x1t, Ut)
-    check_rollout_against_oracle(oracle, dyn, x1, U0, X, A, Bm, dtype, ntraj=min(B, 2))
+    check_rollout_against_oracle(oracle, dyn, x1, U0, X, A, Bm, dtype, ntraj=min(B, 64))
     # the time recursion without the projection (no path dependence at all): every step of the device's rollout against the
     # oracle's f_rocket from the device's own previous state -- 1e-6 in both precisions (single: the double-precision residual
     # refinement of the rollout kernels, csrc/od_units.h::rocket_refine64)
@@ -344,7 +352,8 @@ def check_config5(oracle, lib, device, B=1024, iters=12):
         X, A, Bm, st, _, _ = dyn.rollout(x1t, Ut)
         need = 0x33
         assert ((st & 1) == 1).double().mean().item() > 0.999
-        check_rollout_against_oracle(oracle, dyn, x1, U0, X, A, Bm, dtype, ntraj=2)
+        stats = check_rollout_against_oracle(oracle, dyn, x1, U0, X, A, Bm, dtype, ntraj=64)
+        assert stats["trajectories"] >= min(B, 64)
         sol = IL.ILQR(dyn, obj, T)
         quad = obj.expansion(X, Ut, None, 0.0)
         K, k, dV, bst = sol.backward(A, Bm, quad, 1e-6)
@@ -352,16 +361,15 @@ def check_config5(oracle, lib, device, B=1024, iters=12):
         lxx, luu, lux, lx, lu, VxxT, VxT = [q.cpu().numpy() for q in quad]
         An, Bn, Kn, kn, dVn = A.cpu().numpy(), Bm.cpu().numpy(), K.cpu().numpy(), k.cpu().numpy(), dV.cpu().numpy()
         n, m = 12, 3
-        for b in (0, B // 2, B - 1):
-            Kr, kr, dVr = ilqr_np.backward(
-                np.moveaxis(An[:, :, :, b], 2, 0), np.moveaxis(Bn[:, :, :, b], 2, 0),
-                np.moveaxis(lxx[:, :, b].reshape(n, n, T, order="F"), 2, 0), np.moveaxis(luu[:, :, b].reshape(m, m, T, order="F"), 2, 0),
-                np.moveaxis(lux[:, :, b].reshape(m, n, T, order="F"), 2, 0), lx[:, :, b].T, lu[:, :, b].T,
-                VxxT[:, b].reshape(n, n, order="F"), VxT[:, b], 1e-6)
-            Kd = np.moveaxis(Kn[:, :, b].reshape(m, n, T, order="F"), 2, 0)
-            assert np.abs(Kd - Kr).max() < 1e-8 * max(1.0, np.abs(Kr).max()), (dtype, b)
-            assert np.abs(kn[:, :, b].T - kr).max() < 1e-8 * max(1.0, np.abs(kr).max())
-            assert np.abs(dVn[:, b] - dVr).max() < 1e-8 * max(1.0, np.abs(dVr).max())
+        # ALL B trajectories against the vectorised numpy recursion (oracle/ilqr_np.py::backward_batch)
+        col = lambda M, r, c: np.moveaxis(M.reshape(r, c, T, B, order="F"), (2, 3), (1, 0))          # (r*c, T, B) col-major -> (B, T, r, c)
+        Kr, kr, dVr = ilqr_np.backward_batch(
+            np.moveaxis(An, (2, 3), (1, 0)), np.moveaxis(Bn, (2, 3), (1, 0)), col(lxx, n, n), col(luu, m, m), col(lux, m, n),
+            np.moveaxis(lx, (1, 2), (1, 0)), np.moveaxis(lu, (1, 2), (1, 0)), np.moveaxis(VxxT.reshape(n, n, B, order="F"), 2, 0), VxT.T, 1e-6)
+        Kd = col(Kn, m, n)
+        relb = lambda a, b: np.abs(a - b).reshape(B, -1).max(1) / np.maximum(1.0, np.abs(b).reshape(B, -1).max(1))
+        eK, ek, eV = relb(Kd, Kr), relb(np.moveaxis(kn, (1, 2), (1, 0)), kr), relb(dVn.T, dVr)
+        assert eK.max() < 1e-8 and ek.max() < 1e-8 and eV.max() < 1e-8, (str(dtype), float(eK.max()), float(ek.max()), float(eV.max()))
         kw = dict(max_iter=iters, max_al_iter=1, obj_tol=0.0)
         got = sol.solve(x1t, Ut, **kw)
         ref = IL.ILQR(dyn, obj, T).solve_stepwise(x1t, Ut, **kw)

@@ -57,6 +57,12 @@ def test_rocket_f64(oracle, emu_lib):
     P.check_rocket(oracle, emu_lib, "cpu", 32)
 
 
+def test_rocket_sweep_emulated(oracle, emu_lib):
+    """the GPU tier's rocket sweep (test_gpu_parity_sweep.py::test_rocket_parity_sweep) at 2048 knots on the host build of the same sources"""
+    for dtype in (torch.float64, torch.float32):
+        P.check_rocket_sweep(oracle, emu_lib, "cpu", 2048, 202, dtype)
+
+
 def test_rocket_f32(oracle, emu_lib):
     P.check_rocket(oracle, emu_lib, "cpu", 16, dtype=torch.float32)
 

@@ -96,6 +96,24 @@ def test_parity_sweep(oracle, gpu_lib):
             assert r["grad_rel_median"] < 1e-9, (name, r)
 
 
+def test_rocket_parity_sweep(oracle, gpu_lib):
+    """the rocket path (src/models/rocket/dynamics.jl:101-268; BASELINE config 5 is the one config asked in single precision) at the
+    scale of the mechanical models' sweep: 3 seeds x 8192 knots, double AND single precision, every converged knot -- the dynamics step
+    at 1e-6 / 1e-4 against the oracle, the thrust-cone projection's gradient arbitrated per knot in binary128 at the device's own
+    iterate, every projected control verified against the algorithm's own stopping rule, the chain product against the oracle's
+    dynamics gradient times the arbitrated projection gradient (parity_checks.check_rocket_sweep); the error columns go to
+    gpurun_out/rocket_parity_sweep.json (copied to profiles/ for the round)"""
+    rows = []
+    for dtype in (torch.float64, torch.float32):
+        for seed in SEEDS:
+            rows.append(P.check_rocket_sweep(oracle, gpu_lib, DEV, 8192, seed, dtype))
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    json.dump(rows, open(os.path.join(d, "rocket_parity_sweep.json"), "w"), indent=1)
+    for r in rows:
+        assert r["dyn_converged"] > 0.999 * r["knots"] and r["proj_arbitrated"] > 0.99 * r["knots"] and r["chain_converged"] > 0.99 * r["knots"], r
+
+
 def test_rollout_parity_sweep(oracle, gpu_lib):
     """headline-shaped rollouts (hopper, T = 100) against the oracle's rollouts: the recursion amplifies rounding
     differences through contact-mode switches, so the comparison is knot by knot in time"""
