@@ -269,6 +269,11 @@ int od_ilqr_get(od_ilqr s, double* X, double* U, double* J, double* K, double* k
 /* hist: up to `cap` rows of B costs (row i = costs after iteration i), device pointer; returns the number of rows kept so far
  * (synchronises) or a negative error */
 int od_ilqr_get_history(od_ilqr s, double* hist, int cap);
+/* the decisions behind that history, row i = iteration i, B entries each (device pointers, any may be NULL; same row count and
+ * return value as od_ilqr_get_history): step_index = index into `alphas` of the step size the Armijo test accepted (-1: none, the
+ * regularisation went up instead; -2: the trajectory had converged before this iteration), reg = the trajectory's regularisation
+ * after the iteration, rho = its penalty.  What IterativeLQR prints per iteration with verbose = true (alpha, cost, penalty). */
+int od_ilqr_get_trace(od_ilqr s, int* step_index, double* reg, double* rho, int cap);
 /* per trajectory (device pointers, any may be NULL; asynchronous): flags (bit 0: inner loop converged, bit 1: constraints met to
  * con_tol), violation as of the last od_ilqr_al_update / od_ilqr_solve, penalty rho.  The B problems are independent solves: each
  * has its own regularisation schedule, penalty and flags, and follows the path it would follow in a batch of one. */

@@ -368,6 +368,15 @@ solve!(s::ILQRSolver, x1, U0) = check(ccall((:od_ilqr_solve, LIB), Cint, (Ptr{Cv
 "get_trajectory(solver) -- examples/acrobot.jl:121: X (B x (T+1) x n), U (B x T x m), J (B) device arrays, filled asynchronously"
 get_trajectory!(s::ILQRSolver, X, U, J) =
     check(ccall((:od_ilqr_get, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), s.s, pointer(X), pointer(U), pointer(J), C_NULL, C_NULL))
+"""
+    get_trace!(s, step_index, reg, rho, cap) -> rows
+
+The decisions of every iteration since `initialize!` (what IterativeLQR prints with `verbose = true`): device arrays of `cap x B`
+(`Int32`, `Float64`, `Float64`); row i: index into `alphas` of the accepted step size (-1 none, -2 the problem had converged before),
+the problem's regularisation after the iteration, its penalty.
+"""
+get_trace!(s::ILQRSolver, step_index, reg, rho, cap::Integer) =
+    ccall((:od_ilqr_get_trace, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint), s.s, pointer(step_index), pointer(reg), pointer(rho), cap)
 function info(s::ILQRSolver)
     r = Ref(ILQRInfo(0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0))
     check(ccall((:od_ilqr_get_info, LIB), Cint, (Ptr{Cvoid}, Ref{ILQRInfo}), s.s, r))

@@ -96,6 +96,7 @@ SIGNATURES = {
     "od_ilqr_get": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "od_ilqr_get_history": (C.c_int, [_VP, _VP, C.c_int]),
     "od_ilqr_get_status": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "od_ilqr_get_trace": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int]),
     "od_ilqr_get_info": (C.c_int, [_VP, C.POINTER(IlqrInfo)]),
     "od_bundle_workspace_bytes": (C.c_size_t, [_VP, C.c_long, C.c_int]),
     "od_bundle_grad": (C.c_int, [_VP, C.c_long, C.c_int, _VP, _VP, _VP, _VP, _VP, C.c_size_t, _IP]),

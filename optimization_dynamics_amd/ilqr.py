@@ -576,6 +576,19 @@ class DeviceILQR:
         self.lib.check(self.lib.cdll.od_ilqr_get_status(self._s, _ptr(fl), _ptr(v), _ptr(r)))
         return fl, v, r
 
+    def trace(self):
+        """the decisions of every iteration since init, (iterations, B) each: index of the accepted step size (-1 none, -2 the
+        trajectory had converged before), regularisation after the iteration, penalty (od_ilqr_get_trace)"""
+        dev = self.im.device
+        sel = torch.empty(self.max_hist, self.B, dtype=torch.int32, device=dev)
+        reg = torch.empty(self.max_hist, self.B, dtype=torch.float64, device=dev)
+        rho = torch.empty(self.max_hist, self.B, dtype=torch.float64, device=dev)
+        self.im._use_current_stream()
+        rows = self.lib.cdll.od_ilqr_get_trace(self._s, _ptr(sel), _ptr(reg), _ptr(rho), self.max_hist)
+        if rows < 0:
+            self.lib.check(rows)
+        return sel[:rows], reg[:rows], rho[:rows]
+
     def history(self):
         """(iterations, B): the costs after every iteration since init"""
         H = torch.empty(self.max_hist, self.B, dtype=torch.float64, device=self.im.device)

@@ -25,6 +25,7 @@
 #     out: bundle_<model>_DZ.bin (nq x (2nq+nu) x B)
 using OptimizationDynamics
 using LinearAlgebra
+using Random
 const RoboDojo = OptimizationDynamics.RoboDojo
 
 indir, outdir = ARGS[1], ARGS[2]
@@ -161,5 +162,60 @@ let
     catch e
         println("projection iterate path not written: ", e)
     end
+end
+# iLQR.solve! on the acrobot swing-up of examples/acrobot.jl (`:impact` model, its objective, terminal constraint, solver options
+# :97-107 and initial controls :90-91) -- the per-iteration record that pins the decisions of an AL-iLQR implementation
+# (oracle/ilqr_np.py::solve, od_ilqr_*): the solve is run K times, cut short after k = 1 .. K inner iterations of the first
+# augmented-Lagrangian round (max_iter = k, max_al_iter = 1), and after each the objective (eval_obj: without multiplier terms),
+# the merit as the solver holds it (s_data.obj[1]), the iteration count it reports, the trajectory's terminal violation and the
+# controls are written:
+#     acrobot_ilqr_U0.bin (1 x 100) the initial controls;  acrobot_ilqr_trace.bin (5 x K): k, s_data.iter[1], eval_obj, s_data.obj[1],
+#     |x_T - goal|_inf;  acrobot_ilqr_U.bin (1 x 100 x K) the controls after k iterations;  and acrobot_ilqr_full.bin (4): iterations,
+#     eval_obj, merit, violation of the uncut solve (max_iter = 50, max_al_iter = 20).
+# From consecutive columns the accepted step size of iteration k follows (u_k - u_{k-1} against the feed-forward direction), the
+# cost decrease is there directly.  Only call sites the reference's own example makes are used (examples/acrobot.jl:33-37,74-76,
+# 85-87,92,97-121); if the installed IterativeLQR differs, the block is skipped with a note.
+try
+    iLQR = OptimizationDynamics.IterativeLQR
+    h = 0.05; T = 101
+    im_dyn = ImplicitDynamics(acrobot_impact, h, eval(r_acrobot_impact_func), eval(rz_acrobot_impact_func), eval(rθ_acrobot_impact_func);
+        r_tol=1.0e-8, κ_eval_tol=1.0e-4, κ_grad_tol=1.0e-3, no_friction=true)
+    nx = 2 * acrobot_impact.nq; nu = acrobot_impact.nu
+    ilqr_dyn = iLQR.Dynamics((d, x, u, w) -> f(d, im_dyn, x, u, w), (dx, x, u, w) -> fx(dx, im_dyn, x, u, w),
+                             (du, x, u, w) -> fu(du, im_dyn, x, u, w), nx, nx, nu)
+    model = [ilqr_dyn for t = 1:T-1]
+    x1 = zeros(4); xT = [π; 0.0; π; 0.0]
+    objt(x, u, w) = 0.5 * 0.1 * sum(((x[3:4] - x[1:2]) ./ h) .^ 2) + 0.5 * sum(u .^ 2)
+    objT(x, u, w) = 0.5 * 0.1 * sum(((x[3:4] - x[1:2]) ./ h) .^ 2)
+    obj = [[iLQR.Cost(objt, nx, nu) for t = 1:T-1]..., iLQR.Cost(objT, nx, 0)]
+    terminal_con(x, u, w) = x - xT
+    cons = [[iLQR.Constraint() for t = 1:T-1]..., iLQR.Constraint(terminal_con, nx, 0)]
+    Random.seed!(1)
+    ū = [1.0e-3 * randn(nu) for t = 1:T-1]
+    writearr(joinpath(outdir, "acrobot_ilqr_U0.bin"), reshape(vcat(ū...), 1, T - 1))
+    function run(max_iter, max_al_iter)
+        x̄ = iLQR.rollout(model, x1, ū)
+        solver = iLQR.solver(model, obj, cons, opts=iLQR.Options(linesearch=:armijo, α_min=1.0e-5, obj_tol=1.0e-5, grad_tol=1.0e-5,
+            max_iter=max_iter, max_al_iter=max_al_iter, con_tol=0.001, ρ_init=1.0, ρ_scale=10.0, verbose=false))
+        iLQR.initialize_controls!(solver, ū)
+        iLQR.initialize_states!(solver, x̄)
+        iLQR.reset!(solver.s_data)
+        iLQR.solve!(solver)
+        x_sol, u_sol = iLQR.get_trajectory(solver)
+        J = iLQR.eval_obj(solver.m_data.obj.costs, solver.m_data.x, solver.m_data.u, solver.m_data.w)
+        return Float64(solver.s_data.iter[1]), J, solver.s_data.obj[1], norm(x_sol[T] - xT, Inf), vcat(u_sol[1:T-1]...)
+    end
+    K = 30
+    TR = zeros(5, K); UU = zeros(1, T - 1, K)
+    for k = 1:K
+        it, J, M, v, u = run(k, 1)
+        TR[:, k] = [k, it, J, M, v]; UU[1, :, k] = u
+    end
+    writearr(joinpath(outdir, "acrobot_ilqr_trace.bin"), TR)
+    writearr(joinpath(outdir, "acrobot_ilqr_U.bin"), UU)
+    it, J, M, v, u = run(50, 20)
+    writearr(joinpath(outdir, "acrobot_ilqr_full.bin"), reshape([it, J, M, v], 4, 1))
+catch e
+    println("acrobot iLQR trace not written: ", e)
 end
 println("reference vectors written to ", outdir)

@@ -673,3 +673,99 @@ def check_device_iteration(lib, device, problem="cartpole", B=6, T=15, dtype=tor
     for i in range(h5.shape[0]):
         assert torch.equal(h5[i], got[3][i]), i
     return got, ref
+
+
+# ---- od_ilqr_* against the INDEPENDENT numpy AL-iLQR of oracle/ilqr_np.py (driven by the oracle's dynamics), decision by decision ---------
+def acrobot_example(lib, device, B, T=100, h=0.05):
+    """examples/acrobot.jl:15-111: swing-up, x1 = 0, x_T = [pi, 0, pi, 0] by augmented Lagrangian, 1/2 0.1 |v1|^2 + 1/2 u^2; trajectory b
+    starts from controls 1e-3 randn(seed 1 + b) (:90-91: trajectory 0 is the example's)"""
+    import math
+    import optimization_dynamics_amd as od
+    im = od.ImplicitDynamics(od.acrobot_impact, h, r_tol=1e-8, kappa_eval_tol=1e-4, kappa_grad_tol=1e-3, device=device, lib=lib)
+    I2 = np.eye(2)
+    Q = 0.1 / h ** 2 * np.block([[I2, -I2], [-I2, I2]])
+    xT = np.array([math.pi, 0.0, math.pi, 0.0])
+    obj = IL.QuadraticObjective(Q, np.eye(1), Q, x_ref=np.zeros(4), goal_idx=[0, 1, 2, 3], goal=xT, device=device)
+    U0 = np.stack([1e-3 * np.random.default_rng(1 + b).normal(size=(1, T)) for b in range(B)], axis=-1)
+    return im, obj, np.zeros((4, B)), U0
+
+
+ORACLE_CASES = {
+    # name: (builder, T, solver options, J tolerance while the decisions agree, iterations that must agree (None: all), final tolerance)
+    "cartpole": dict(T=15, kw=dict(max_iter=8, max_al_iter=2, obj_tol=1e-7, con_tol=1e-4), tolJ=1e-8, need=None),
+    "cartpole_constrained": dict(T=25, kw=dict(max_iter=10, max_al_iter=4, obj_tol=1e-7, con_tol=1e-4), tolJ=1e-8, need=None),
+    # the swing-up passes through joint-limit impacts: a contact-mode switch amplifies the 1e-12 between two implementations of one
+    # solve to 1e-5 in a later cost (both stay valid solves of the task: same outcome, DESIGN.md section 7)
+    "acrobot": dict(T=100, kw=dict(max_iter=50, max_al_iter=20, obj_tol=1e-5, con_tol=1e-3), tolJ=1e-8, need=30),
+    "rocket": dict(T=20, kw=dict(max_iter=10, max_al_iter=1, obj_tol=1e-7, con_tol=1e-4), tolJ=1e-8, need=None),
+    # with the thrust-cone projection on the path every control is a kappa_tol = 1e-4 accurate end point of a line search that
+    # compares rounding noise (parity_checks.check_rocket_sweep): costs agree to that level until an Armijo test lands on the other side
+    "rocket_projected": dict(T=20, kw=dict(max_iter=10, max_al_iter=1, obj_tol=1e-7, con_tol=1e-4), tolJ=2e-3, need=2),
+}
+
+
+def check_against_numpy_oracle(oracle, lib, device, case, B=8, seed=1):
+    """od_ilqr_solve on B problems against oracle/ilqr_np.py::solve on each of them: the accepted step index, the regularisation after
+    the iteration, the penalty and the cost, iteration by iteration (od_ilqr_get_trace / od_ilqr_get_history), then the final
+    trajectory and flags.  -> statistics (asserted here)"""
+    from oracle import ilqr_np as N
+    from optimization_dynamics_amd import rocket as rk
+    cfg = ORACLE_CASES[case]
+    T, kw = cfg["T"], cfg["kw"]
+    roll = None
+    if case == "cartpole":
+        im, obj, x1, U0 = cartpole_problem(lib, device, B, T, seed=seed)
+        step, lin = N.mechanical_dynamics(P.make_sim(oracle, "cartpole_friction"))
+    elif case == "cartpole_constrained":
+        im, obj, x1, U0 = constrained_problem(lib, device, "cartpole", B, T, seed=seed)
+        step, lin = N.mechanical_dynamics(P.make_sim(oracle, "cartpole_friction"))
+    elif case == "acrobot":
+        im, obj, x1, U0 = acrobot_example(lib, device, B, T)
+        step, lin = N.mechanical_dynamics(oracle.make_sim("acrobot_impact", 0.05, kappa_tol=1e-4, kappa_grad_tol=1e-3))
+    else:
+        im, obj, x1, U0 = rocket_problem(lib, device, B, T, seed=seed)
+        if case == "rocket":
+            im = rk.RocketDynamics(im.info, project=False)
+        step, lin, roll = N.rocket_dynamics(0.05, 12.5, project=(case == "rocket_projected"))
+    sol = IL.ILQR(im, obj, T)
+    X, U, J, hist = sol.solve(torch.tensor(x1, device=device), torch.tensor(U0, device=device), **kw)
+    d = sol._dev
+    sel, reg, rho = [a.cpu().numpy() for a in d.trace()]
+    H = torch.stack(hist).cpu().numpy() if len(hist) else np.zeros((0, B))
+    flags, viol, pen = [a.cpu().numpy() for a in d.status()]
+    Xn, Un = X.cpu().numpy(), U.cpu().numpy()
+    f = lambda t: None if t is None else t.cpu().numpy()
+    stats = dict(case=case, problems=B, horizon=T, agreeing_iterations=[], iterations_device=[], iterations_oracle=[], cost_rel_max_while_agreeing=0.0,
+                 final_cost_rel=[], final_state_diff=[], flags_equal=0)
+    for b in range(B):
+        p = N.Problem(step, lin, f(obj.Q), f(obj.R), f(obj.QT), f(obj.x_ref), goal_idx=f(obj.goal_idx), goal=f(obj.goal), stage=obj.stage, terminal=obj.terminal)
+        r = N.solve(p, x1[:, b], U0[:, :, b].T, alphas=tuple(sol.alphas.cpu().tolist()), reg0=sol.reg, c1=sol.c1, rollout_fn=roll, **kw)
+        L = r["log"]
+        rows = [i for i in range(sel.shape[0]) if sel[i, b] != -2]              # the iterations trajectory b took part in
+        nag = 0
+        for l, i in zip(L, rows):
+            same = l["step"] == sel[i, b] and abs(l["reg"] - reg[i, b]) <= 1e-12 * reg[i, b] and abs(l["rho"] - rho[i, b]) <= 1e-12 * max(1.0, rho[i, b])
+            eJ = abs(l["J"] - H[i, b]) / max(1.0, abs(l["J"]))
+            if not (same and eJ <= cfg["tolJ"]):
+                break
+            nag += 1
+            stats["cost_rel_max_while_agreeing"] = max(stats["cost_rel_max_while_agreeing"], float(eJ))
+        stats["agreeing_iterations"].append(nag); stats["iterations_device"].append(len(rows)); stats["iterations_oracle"].append(len(L))
+        fl_o = (1 if r["done"] else 0) | (2 if r["al_done"] else 0)
+        stats["flags_equal"] += int(fl_o == int(flags[b]))
+        eX = float(np.abs(r["X"].T - Xn[:, :, b]).max())
+        stats["final_state_diff"].append(eX)
+        Jd, Jo = float(J[b].item()), r["J"]
+        stats["final_cost_rel"].append(abs(Jd - Jo) / max(1e-12, abs(Jo)))
+        if cfg["need"] is None:
+            # every decision of every iteration, and the same trajectory at the end
+            assert nag == len(L) == len(rows), (case, b, nag, len(L), len(rows))
+            assert fl_o == int(flags[b]) and eX < 1e-6 * max(1.0, np.abs(r["X"]).max()), (case, b, fl_o, int(flags[b]), eX)
+            assert abs(r["violation"] - viol[b]) <= 1e-8 + 1e-6 * abs(r["violation"]) and abs(r["rho"] - pen[b]) <= 1e-9 * max(1.0, pen[b])
+        else:
+            # the leading iterations decision by decision; then two valid solves of the same task: same outcome
+            assert nag >= min(cfg["need"], len(L)), (case, b, nag)
+            assert r["al_done"] == bool(flags[b] & 2) or not obj.constrained, (case, b)
+            assert abs(Jd - Jo) <= 0.1 * abs(Jo), (case, b, Jd, Jo)
+            assert abs(len(L) - len(rows)) <= max(3, 0.25 * len(L)), (case, b, len(L), len(rows))
+    return stats

@@ -42,9 +42,18 @@ def test_finite_difference_jacobians_against_implicit_gradients(oracle, emu_lib)
 
 
 @pytest.mark.gpu
-def test_acrobot_swing_up_on_the_device(gpu_lib):
+def test_acrobot_swing_up_on_the_device(oracle, gpu_lib):
     """examples/acrobot.jl (T = 101, terminal equality constraint by augmented Lagrangian, options of :98-108) through od_ilqr_solve,
-    64 problems: every one reaches the goal to con_tol; objective in the range the CPU validator finds (77-80)"""
+    64 problems: every one reaches the goal to con_tol; and problem 0 (the validator's initial controls) against the numpy AL-iLQR on
+    the CPU oracle with implicit gradients (oracle/fd_validator.py::solve -> the same loop as oracle/ilqr_np.py::solve): the same
+    task solved to the same constraint tolerance with an objective within 5 % -- the decisions of the first ~50 iterations are
+    compared one by one in tests/test_ilqr.py::test_solver_decisions_against_the_numpy_oracle_gpu, after which a joint-limit impact
+    amplifies the 1e-12 between the two implementations of the step"""
+    from oracle import fd_validator as V
     J, viol, info = _device_solution(gpu_lib, "cuda:0", 64)
     assert viol.max() < 1e-3 and info.al_done == 1, (viol.max(), info.al_done)
-    assert (J > 60).all() and (J < 100).all(), (J.min(), J.max())
+    imp = V.solve("implicit")
+    assert imp["violation"] < 1e-3
+    assert abs(J[0] - imp["objective"]) < 0.05 * imp["objective"], (J[0], imp["objective"])
+    # the other 63 start from other random controls of the same size: the same swing-up, objectives in a band around the validator's
+    assert (np.abs(J - imp["objective"]) < 0.25 * imp["objective"]).all(), (J.min(), J.max(), imp["objective"])

@@ -189,3 +189,26 @@ def test_hopper_example_on_the_device_cpu(emu_lib):
 @pytest.mark.gpu
 def test_hopper_example_on_the_device_gpu(gpu_lib):
     C.check_hopper_example(gpu_lib, "cuda:0", B=64, need=0.9)
+
+
+# ---- od_ilqr_solve against the independent numpy AL-iLQR driven by the oracle's dynamics (oracle/ilqr_np.py::solve): every decision ------------
+@pytest.mark.parametrize("case", ["cartpole", "cartpole_constrained", "rocket", "rocket_projected"])
+def test_solver_decisions_against_the_numpy_oracle_cpu(oracle, emu_lib, case):
+    C.check_against_numpy_oracle(oracle, emu_lib, "cpu", case, B=4)
+
+
+def test_acrobot_solver_decisions_against_the_numpy_oracle_cpu(oracle, emu_lib):
+    C.check_against_numpy_oracle(oracle, emu_lib, "cpu", "acrobot", B=1)
+
+
+@pytest.mark.gpu
+def test_solver_decisions_against_the_numpy_oracle_gpu(oracle, gpu_lib):
+    """cartpole with two augmented-Lagrangian rounds, the constrained cartpole (stage and terminal rows), the acrobot swing-up of
+    examples/acrobot.jl and the rocket in double precision (with and without the thrust-cone projection), 8 problems each: accepted
+    step index, regularisation, penalty and cost of every iteration, final trajectory and flags; gpurun_out/ilqr_oracle_parity.json"""
+    import json
+    import os
+    out = [C.check_against_numpy_oracle(oracle, gpu_lib, "cuda:0", case, B=8) for case in ("cartpole", "cartpole_constrained", "acrobot", "rocket", "rocket_projected")]
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    json.dump(out, open(os.path.join(d, "ilqr_oracle_parity.json"), "w"), indent=1)
