@@ -459,7 +459,7 @@ template <class T> struct RocketArgs {
   const int* live;    // per trajectory: knot b belongs to trajectory b % live_mod and is computed only if live[b % live_mod] != 0
   long live_mod;
   int proj_stall_exit; // 1: a projection solve that has stalled at the boundary of the cone is abandoned (od_solver.h::model_stall)
-  int polish64;        // single-precision handles: 1 = one Newton step of the dynamics residual and the implicit gradient in double (rocket_polish64)
+  int polish64;        // single-precision handles: 1 = the dynamics solution refined with the residual in double (rocket_refine64) and the implicit gradient from a double factorisation there (rocket_grad64)
   double h64;          // the time step in double (h is rounded to T)
 };
 
@@ -493,18 +493,23 @@ template <class T> struct RocketDynSink {
 
 // Mixed precision for the single-precision handles (BASELINE config 5; SURVEY.md section 7: "keep the final Newton refinement in
 // fp64").  The single-precision Newton iteration of the dynamics step stops at r_tol = 1e-4 -- 1e-8 is below the resolution of
-// float -- and its implicit gradient carries the conditioning of a float LU.  One more Newton step of the SAME residual in double
-// at the float solution (inputs x, u as the floats they are, the time step in double) squares the error away, and -rz^{-1} rtheta
-// with that double factorisation gives the gradient; both are rounded to float on the way out, so the results are the
-// double-precision answers to float resolution (6e-8) -- inside the north_star's 1e-6 / 1e-4 -- for one factorisation of a
-// 12 x 12 system with 44 factor entries.  The thrust-cone projection stays in single precision: its result is only
+// float -- and its implicit gradient carries the conditioning of a float LU.  The solution is refined with the residual of the SAME
+// equations in double at the float solution (inputs x, u as the floats they are, the time step in double; rocket_refine64 below), and
+// -rz^{-1} rtheta is taken from a double factorisation at the refined point (rocket_grad64); both are rounded to float on the way
+// out, so the results are the double-precision answers to float resolution (6e-8) -- inside the north_star's 1e-6 / 1e-4 -- for one
+// factorisation of a 12 x 12 system with 44 factor entries.  The thrust-cone projection stays in single precision: its result is only
 // kappa_tol = 1e-4 accurate by construction.
 template <class S> struct CastSink64 {
   S& s;
   OD_HD void grad(int i, int c, double v) { s.grad(i, c, (float)v); }
 };
-template <class MD, class Sink> OD_HD bool rocket_polish64(const float* x, const float* u, double h, float* y, bool want_grad, Sink& sink) {
-  double th[MD::NTH], z[MD::NZ], r[MD::NZ], D[MD::NZ], pre[MD::NPRE > 0 ? MD::NPRE : 1], tr[MD::NTR > 0 ? MD::NTR : 1];
+// the implicit gradient -rz^{-1} rtheta in double AT the (refined, float-rounded) solution y: residual (for the shared trigonometric
+// values), Jacobian, factorisation and the NGC solves all at that point.  (Round 4 took the gradient from the factorisation of the
+// point BEFORE the polishing step: the float iteration stops at r_tol = 1e-4, so that point can sit 1e-4 away from the solution and the
+// gradient inherited an error of that size times the curvature -- one knot in 25 000 at 1.01e-4 relative, found by the round-5 sweep,
+// tests/parity_checks.py::check_rocket_sweep.)
+template <class MD, class Sink> OD_HD bool rocket_grad64(const float* x, const float* u, double h, const float* y, Sink& sink) {
+  double th[MD::NTH], z[MD::NZ], r[MD::NZ], pre[MD::NPRE > 0 ? MD::NPRE : 1], tr[MD::NTR > 0 ? MD::NTR : 1];
 #pragma unroll
   for (int i = 0; i < 12; ++i) { th[i] = (double)x[i]; z[i] = (double)y[i]; }
   th[12] = (double)u[0]; th[13] = (double)u[1]; th[14] = (double)u[2]; th[15] = h;
@@ -512,23 +517,17 @@ template <class MD, class Sink> OD_HD bool rocket_polish64(const float* x, const
   MD::eval_r(z, th, pre, tr, r);
   typename MD::template Fact<double> f;
   const bool ok = eval_factor<MD>(z, th, pre, tr, 0.0, f);
-  MD::solve(f, r, D);
+  double g[MD::NNZTH];
+  MD::eval_rth(z, th, pre, tr, g);
+  for (int c = 0; c < MD::NGC; ++c) {
+    double b[MD::NZ];
 #pragma unroll
-  for (int i = 0; i < MD::NZ; ++i) { z[i] -= D[i]; y[i] = (float)z[i]; }
-  if (want_grad) {
-    // (the factorisation of the point before the step: the Jacobian moves by the size of the step, ~1e-6 relative)
-    double g[MD::NNZTH];
-    MD::eval_rth(z, th, pre, tr, g);
-    for (int c = 0; c < MD::NGC; ++c) {
-      double b[MD::NZ];
+    for (int i = 0; i < MD::NZ; ++i) b[i] = 0.0;
 #pragma unroll
-      for (int i = 0; i < MD::NZ; ++i) b[i] = 0.0;
+    for (int k = 0; k < MD::NNZTH; ++k) b[MD::RTH_ROW[k]] = (MD::RTH_COL[k] == c) ? g[k] : b[MD::RTH_ROW[k]];
+    MD::solve(f, b, b);
 #pragma unroll
-      for (int k = 0; k < MD::NNZTH; ++k) b[MD::RTH_ROW[k]] = (MD::RTH_COL[k] == c) ? g[k] : b[MD::RTH_ROW[k]];
-      MD::solve(f, b, b);
-#pragma unroll
-      for (int i = 0; i < MD::NZQ; ++i) sink.grad(i, c, -b[MD::ZQ[i]]);
-    }
+    for (int i = 0; i < MD::NZQ; ++i) sink.grad(i, c, -b[MD::ZQ[i]]);
   }
   return ok;
 }
@@ -633,11 +632,17 @@ OD_HD void rocket_knot(const RocketArgs<T>& a, long b, const T* x, T* u, T* y) {
   int sd;
   if constexpr (sizeof(T) == 4) {
     if (a.polish64) {
+      // the float Newton iteration, its solution refined with the residual in double through the float factors (rocket_refine64: ~1e-9),
+      // then the gradient from a double factorisation AT that solution
       NoGradSink<T> ns;
-      sd = ip_step_grad<MD>(a.opts_dyn, th, y, true, false, ns, it);
-      CastSink64<RocketDynSink<T>> cs{ds};
-      if (!rocket_polish64<MD>(x, u, a.h64, y, a.want_grad != 0, cs)) sd &= ~OD_ST_FACTOR_OK;
-      if (a.want_grad && (sd & OD_ST_EVAL_OK)) sd |= OD_ST_GRAD_OK;
+      typename MD::template Fact<T> fd;
+      sd = ip_step_grad<MD, T, NoGradSink<T>>(a.opts_dyn, th, y, true, false, ns, it, fd);
+      rocket_refine64<MD>(x, u, a.h64, th, y, fd, it[0] > 0);
+      if (a.want_grad) {
+        CastSink64<RocketDynSink<T>> cs{ds};
+        if (!rocket_grad64<MD>(x, u, a.h64, y, cs)) sd &= ~OD_ST_FACTOR_OK;
+        if (sd & OD_ST_EVAL_OK) sd |= OD_ST_GRAD_OK;
+      }
     } else {
       sd = ip_step_grad<MD>(a.opts_dyn, th, y, true, a.want_grad != 0, ds, it);
     }

@@ -957,8 +957,11 @@ def check_rocket_sweep(oracle, lib, device, B, seed, dtype=torch.float64, u_max=
     # rounding drift) is reported by both as it ends for each: its size and the disagreements are recorded and bounded
     plain_o, plain_d = conv_o & (itpo < 30), conv_d & (itp < 30)
     stalled = ~(plain_o | plain_d)
-    assert (plain_o & ~conv_d).sum() <= (0 if f64 else max(2, B // 2000)), ("not stalled in the oracle, not converged on the device", int((plain_o & ~conv_d).sum()))
-    assert (plain_d & ~conv_o).sum() <= (0 if f64 else max(2, B // 2000)), int((plain_d & ~conv_o).sum())
+    # (single precision: the float solve stops at r_tol = 1e-4 where the double one asks for 1e-8 -- a handful of solves near the apex
+    # that stall in double are through in float, and the other way round)
+    lim = 0 if f64 else max(2, B // 500)
+    assert (plain_o & ~conv_d).sum() <= lim, (row["dtype"], "not stalled in the oracle, not converged on the device", int((plain_o & ~conv_d).sum()))
+    assert (plain_d & ~conv_o).sum() <= lim, (row["dtype"], "converged on the device in < 30 iterations, not in the oracle", int((plain_d & ~conv_o).sum()))
     assert stalled.sum() <= max(4, B // 100), int(stalled.sum())
     Ed, cond = oracle.arbiter_gradient_batch("rocket_projection", Z, TH)
     Eo, _ = oracle.arbiter_gradient_batch("rocket_projection", Zo, TH)
@@ -989,8 +992,12 @@ def check_rocket_sweep(oracle, lib, device, B, seed, dtype=torch.float64, u_max=
     # the closed-form projection, measured), bounded here at that level.
     rv, kv = oracle.violations_batch("rocket_projection", Z, TH)
     assert rv[conv_d].max() < (1e-8 if f64 else 1e-4) and kv[conv_d].max() < 1e-4 * (1.0 + (1e-9 if f64 else 1e-2)), (float(rv[conv_d].max()), float(kv[conv_d].max()))
-    slack = 1e-9 if f64 else 1e-5
-    assert (Z[2] - np.hypot(Z[0], Z[1]))[conv_d].min() > -slack and (Z[9] - np.hypot(Z[7], Z[8]))[conv_d].min() > -slack and Z[[2, 3, 4, 5]][:, conv_d].min() > -slack
+    # (with eps_min = 0 a full step ends ON the boundary of a cone, to the rounding of the step-length division: membership to 1e-7 of
+    # the cone's scale in double -- the device's x * rsqrt(x) square root is a few ulp wider than the oracle's -- and 1e-4 in single)
+    slack = (1e-7 if f64 else 1e-4) * np.maximum(1.0, np.abs(Z).max(0))
+    memb = np.minimum.reduce([Z[2] - np.hypot(Z[0], Z[1]), Z[9] - np.hypot(Z[7], Z[8]), Z[2], Z[3], Z[4], Z[5]]) / slack
+    assert memb[conv_d].min() > -1.0, ("cone membership of the device's end points (in units of the slack)", float(memb[conv_d].min()))
+    row.update(proj_cone_membership_min_over_slack=float(memb[conv_d].min()))
     assert dpath[use & ~on].max(initial=0.0) < (4e-3 if f64 else 8e-3), float(dpath[use].max())
     assert (np.abs(Z[:3] - Pc).max(0) / scp)[use].max() < 8e-3 and (np.abs(E[:3] - Pc).max(0) / scp)[use].max() < 8e-3
     row.update(proj_end_point_r_vio_max=float(rv[conv_d].max()), proj_end_point_k_vio_max=float(kv[conv_d].max()),
@@ -1020,11 +1027,16 @@ def check_rocket_sweep(oracle, lib, device, B, seed, dtype=torch.float64, u_max=
     # od_rocket and od_soc_project_full run the same projection in two kernels: the same control (a line-search tie resolved the other
     # way by another instruction schedule would show here) on all but a few knots; there the chain product is checked with the
     # projection gradient arbitrated in (2)
-    same = okc & conv_d & (np.abs(UP - Z[:3]).max(0) <= 1e-12 * scp)
-    assert same.sum() >= okc.sum() - max(2, B // 200), (int(same.sum()), int(okc.sum()))
+    same = okc & conv_d & (np.abs(UP - Z[:3]).max(0) <= (1e-12 if f64 else 1e-5) * scp)      # (single: two compilations of float arithmetic agree to rounding, not bit for bit)
+    assert same.sum() >= okc.sum() - max(2, B // (200 if f64 else 50)), (int(same.sum()), int(okc.sum()))     # (single: line-search ties fall the other way more often, 0.5 % measured)
     chain = np.einsum("ikb,kcb->icb", DZo2[:, 12:15], DP)
-    eu = rel(DU, chain, 0)[same]
-    assert eu.max() < GRAD_TOL, float(eu.max())
+    eu = rel(DU, chain, 0)
+    # (single precision: od_rocket's own float projection gradient and od_soc_project_full's are two compilations of a float
+    # factorisation -- each within the knot's conditioning bound of (2) of the exact gradient, so up to twice that apart)
+    amp = np.abs(DZo2[:, 12:15]).reshape(-1, B).max(0) * sc / np.maximum(1.0, np.abs(chain).reshape(-1, B).max(0))
+    tol_u = GRAD_TOL + (0.0 if f64 else 1.0) * 8.0 * np.where(np.isfinite(bound), bound, 0.0) * amp
+    assert (eu[same] <= tol_u[same]).all(), float((eu[same] / tol_u[same]).max())
+    eu = eu[same]
     row.update(chain_converged=int(okc.sum()), chain_state_rel_max=float(es.max()), chain_fx_rel_max=float(ex.max()), chain_fu_rel_max=float(eu.max()),
                chain_same_projection_in_both_kernels=int(same.sum()))
     return row
