@@ -57,3 +57,24 @@ def test_acrobot_swing_up_on_the_device(oracle, gpu_lib):
     assert abs(J[0] - imp["objective"]) < 0.05 * imp["objective"], (J[0], imp["objective"])
     # the other 63 start from other random controls of the same size: the same swing-up, objectives in a band around the validator's
     assert (np.abs(J - imp["objective"]) < 0.25 * imp["objective"]).all(), (J.min(), J.max(), imp["objective"])
+
+
+def test_direct_method_against_ilqr_on_the_hopper_gait(oracle):
+    """SURVEY.md 8(f).4, the direct-method leg (examples/comparisons/hopper.jl:57-162,290-303,318-357) on the CPU oracle: the hopper's
+    gait task as one nonlinear programme over configurations, controls, contact impulses and complementarity slacks with the oracle's
+    residual as constraints (scipy trust-constr standing in for Ipopt, which is absent like MuJoCo), started from the iLQR solution,
+    priced under the iLQR cost beside it (oracle/direct_validator.py).  The two methods agree on the task: the direct solution is
+    feasible, its objective within a few per cent of the iLQR solution's -- it may not be beaten by much by a method that is handed the
+    iLQR answer as a start --, and its controls drive the time-stepping simulator along the same motion."""
+    from oracle import direct_validator as D
+    r = D.compare()
+    print("hopper gait: iLQR J = %.4f (violation %.1e, %d iterations); direct J = %.4f (equality rows %.1e, slack max %.1e, %d iterations, optimality %.1e)"
+          % (r["ilqr_objective"], r["ilqr_violation"], r["ilqr_iterations"], r["direct_objective"], r["direct_equality_violation"], r["direct_slack_max"],
+             r["direct_iterations"], r["direct_optimality"]))
+    assert r["ilqr_violation"] < 1e-3 and r["travel_ilqr"] >= 0.5 - 1e-3
+    assert r["direct_equality_violation"] < 1e-5 and r["direct_inequality_violation"] < 1e-5 and r["direct_terminal_violation"] < 1e-5
+    assert r["direct_slack_max"] < 1e-3                              # complementarity at the time-stepping simulator's own kappa_tol = 1e-4 level
+    assert r["travel_direct"] >= 0.5 - 1e-5
+    assert abs(r["direct_objective"] - r["ilqr_objective"]) < 0.05 * r["ilqr_objective"], (r["direct_objective"], r["ilqr_objective"])
+    assert r["direct_objective"] > 0.9 * r["ilqr_objective"]
+    assert r["rollout_converged"] and r["rollout_of_direct_controls_state_diff"] < 2e-2, r["rollout_of_direct_controls_state_diff"]
