@@ -145,12 +145,12 @@ def config3(dev, cpu=True):
     return out
 
 
-def _config5_one(dev, which, dtype, cpu):
+def _config5_one(dev, which, dtype, cpu, B=4096):
     import ilqr_checks as C
     import optimization_dynamics_amd as od
     from optimization_dynamics_amd import interior_point as IP
     lib = od.default_library()
-    B, T = 4096, 60
+    T = 60
     if which == "examples/rocket.jl inputs":
         dyn, obj, x1, U0 = C.config5_problem(lib, dev, B, dtype=dtype)
     else:
@@ -242,6 +242,15 @@ def config5(dev, cpu=True):
             r, J, _ = _config5_one(dev, which, dtype, cpu)
             r["cost_mean_after_10_iterations"] = float(J.mean().item())
             out[key] = r
+    # the same iteration at the batch that fills the chip's 1024 SIMDs with one wavefront of candidates each (5957 problems x 11 step sizes =
+    # 65 527 candidates = 1024 wavefronts; at 4096 problems 704 wavefronts leave 30 % of the SIMDs idle by construction): where the forward
+    # pass's roofline fraction stands when occupancy is not the limit
+    for dtype in (torch.float32, torch.float64):
+        try:
+            r, J, _ = _config5_one(dev, "hover-thrust test problem", dtype, cpu, B=5957)
+            out["chip-filling batch (5957 problems), hover-thrust test problem, %s" % ("fp32" if dtype == torch.float32 else "fp64")] = r
+        except Exception as e:
+            out["chip-filling batch, %s" % dtype] = {"error": repr(e)}
     try:
         out["riccati_pass"] = _riccati_pass(dev)
     except Exception as e:

@@ -252,6 +252,36 @@ int od_ilqr_set_objective(od_ilqr s, const double* Q, const double* R, const dou
  * Host pointers; call before od_ilqr_init.  (0, 0, NULL, ...) removes them. */
 int od_ilqr_set_constraints(od_ilqr s, int ns, int ns_ineq, const double* Cs, const double* Ds, const double* ds,
                             int nt, int nt_ineq, const double* Ct, const double* dt);
+/* ---- parameter stage: a first stage of its own dimensions, nonlinear constraints on it (examples/hopper.jl) ----------------------
+ * examples/hopper.jl:16-50,52-175,234-266 optimises, with the controls, the two initial configurations theta = [q1; q2] of the
+ * hopper's gait: its first stage takes theta as ADDITIONAL CONTROLS (x_1 in R^8 fixed, u_1 = [u; theta] in R^10, f1: [q2; q3; theta] in
+ * R^16), the later stages carry theta in their state (R^16, ft), the first stage has a cost and nonlinear constraints on theta
+ * (stage1_con: the foot does not move between the two configurations) and the terminal constraint couples x_T with theta
+ * (terminal_con: half a metre further, otherwise the pose the gait started from).  od_ilqr_set_parameter_stage poses that problem
+ * for a mechanical handle (2 n <= 16, m + n <= 12): SLOT 0 of every trajectory is theta -- x1 of od_ilqr_init / od_ilqr_solve is its
+ * initial value, X[:, 0] of od_ilqr_get the optimised one --; the objective of od_ilqr_set_objective applies to slots 1 .. T (Q, QT)
+ * and to every control (R); slot 0 costs 1/2 theta' diag(w_theta) theta + cost_const instead; `constraint` names a generated
+ * function c(theta; p) = 0 (python -m optimization_dynamics_amd.codegen --add-constraint spec.py, the counterpart of
+ * iLQR.Constraint(f, nx, nu) differentiating a user's function; od_constraint_id("hopper_foot") is the one of the example); the
+ * terminal rows Ct_x x_T + Ct_theta theta - dt (nt x n col-major each, the first nt_ineq inequalities <= 0) join the augmented
+ * Lagrangian like the rows of od_ilqr_set_constraints, whose stage rows keep applying to (slot state, control) at every knot.  The
+ * iteration is the one described above -- Riccati pass on the model of the reference's formulation at its dimensions (2 n states,
+ * m + n controls), candidates rolled out from their own theta + alpha dtheta by the kernels of the path -- with no host
+ * synchronisation.  Host pointers; call before od_ilqr_init; NULL removes the stage. */
+typedef struct {
+  int constraint;            /* id of a generated constraint function on theta (od_constraint_id), -1: none; all rows equalities */
+  int n_p; const double* p;  /* its parameters (od_constraint_dims) */
+  const double* w_theta;     /* n weights of the cost 1/2 theta' diag(w) theta (obj1's weights on u[3:10], examples/hopper.jl:209) */
+  double cost_const;         /* added to every cost (the first stage's cost of the fixed x_1) */
+  int nt, nt_ineq;           /* terminal rows coupling x_T and theta */
+  const double *Ct_x, *Ct_theta, *dt;
+} od_ilqr_parameter_stage;
+int od_ilqr_set_parameter_stage(od_ilqr s, const od_ilqr_parameter_stage* ps);
+/* registry of the generated constraint functions (csrc/gen/con_list.h): rows nc on nx variables with np parameters */
+int od_num_constraints(void);
+int od_constraint_id(const char* name);       /* -1 if unknown */
+const char* od_constraint_name(int id);
+int od_constraint_dims(int id, int* nc, int* nx, int* np);
 /* initialize_controls! + rollout + first linearisation and cost (examples/acrobot.jl:108-113): x1 n per trajectory, U0 m per knot
  * (T*B knots), doubles on the device.  Resets multipliers, penalty, regularisation and counters.  Asynchronous. */
 int od_ilqr_init(od_ilqr s, const double* x1, const double* U0);

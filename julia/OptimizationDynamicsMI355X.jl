@@ -354,6 +354,27 @@ function set_constraints!(s::ILQRSolver; Cs=zeros(0, 0), Ds=zeros(0, 0), ds=Floa
                 s.s, length(ds), n_stage_ineq, Matrix{Float64}(Cs), Matrix{Float64}(Ds), Float64.(collect(ds)),
                 length(dt), n_terminal_ineq, Matrix{Float64}(Ct), Float64.(collect(dt))))
 end
+struct ILQRParameterStage          # od_ilqr_parameter_stage
+    constraint::Cint; n_p::Cint; p::Ptr{Cdouble}; w_theta::Ptr{Cdouble}; cost_const::Cdouble
+    nt::Cint; nt_ineq::Cint; Ct_x::Ptr{Cdouble}; Ct_theta::Ptr{Cdouble}; dt::Ptr{Cdouble}
+end
+"""
+    set_parameter_stage!(s; w_theta, constraint="", p, Ct_x, Ct_theta, dt, n_terminal_ineq, cost_const)
+
+The first stage of examples/hopper.jl (:52-101,165-175,234-266): the initial configurations θ = [q1; q2] are optimised with the controls.
+Slot 1 of every trajectory is θ (x1 of `initialize!` / `solve!` its initial value); it costs ½ θ'diag(w_theta)θ + cost_const, obeys the
+generated constraint function `constraint` (c(θ; p) = 0, e.g. "hopper_foot": stage1_con without its control limits) and enters the terminal
+rows `Ct_x x_T + Ct_theta θ - dt` (the first `n_terminal_ineq` inequalities ≤ 0: terminal_con).
+"""
+function set_parameter_stage!(s::ILQRSolver; w_theta, constraint="", p=Float64[], Ct_x=zeros(0, 0), Ct_theta=zeros(0, 0), dt=Float64[], n_terminal_ineq=0, cost_const=0.0)
+    cid = isempty(constraint) ? Cint(-1) : ccall((:od_constraint_id, LIB), Cint, (Cstring,), constraint)
+    (isempty(constraint) || cid >= 0) || error("constraint function $constraint is not in the library")
+    w = Float64.(collect(w_theta)); pp = Float64.(collect(p)); cx = Matrix{Float64}(Ct_x); ct = Matrix{Float64}(Ct_theta); d = Float64.(collect(dt))
+    GC.@preserve w pp cx ct d begin
+        ps = Ref(ILQRParameterStage(cid, length(pp), pointer(pp), pointer(w), cost_const, length(d), n_terminal_ineq, pointer(cx), pointer(ct), pointer(d)))
+        check(ccall((:od_ilqr_set_parameter_stage, LIB), Cint, (Ptr{Cvoid}, Ref{ILQRParameterStage}), s.s, ps))
+    end
+end
 "per problem: flags (bit 0 inner loop converged, bit 1 constraints met), violation, penalty -- device arrays of length B"
 get_status!(s::ILQRSolver, flags, violation, penalty) =
     check(ccall((:od_ilqr_get_status, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), s.s, pointer(flags), pointer(violation), pointer(penalty)))

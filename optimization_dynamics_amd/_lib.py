@@ -34,6 +34,13 @@ class IlqrOptions(C.Structure):
                 ("project", C.c_int), ("history", C.c_int), ("proj_stall_exit", C.c_int), ("rho_max", C.c_double)]
 
 
+class IlqrParameterStage(C.Structure):
+    """od_ilqr_parameter_stage"""
+    _fields_ = [("constraint", C.c_int), ("n_p", C.c_int), ("p", C.POINTER(C.c_double)), ("w_theta", C.POINTER(C.c_double)),
+                ("cost_const", C.c_double), ("nt", C.c_int), ("nt_ineq", C.c_int), ("Ct_x", C.POINTER(C.c_double)),
+                ("Ct_theta", C.POINTER(C.c_double)), ("dt", C.POINTER(C.c_double))]
+
+
 class IlqrInfo(C.Structure):
     """od_ilqr_info"""
     _fields_ = [("iterations", C.c_int), ("al_iterations", C.c_int), ("done", C.c_int), ("al_done", C.c_int),
@@ -89,6 +96,11 @@ SIGNATURES = {
     "od_ilqr_set_objective": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "od_ilqr_set_constraints": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "od_ilqr_set_parameter_stage": (C.c_int, [_VP, C.POINTER(IlqrParameterStage)]),
+    "od_num_constraints": (C.c_int, []),
+    "od_constraint_id": (C.c_int, [C.c_char_p]),
+    "od_constraint_name": (C.c_char_p, [C.c_int]),
+    "od_constraint_dims": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "od_ilqr_init": (C.c_int, [_VP, _VP, _VP]),
     "od_ilqr_iterate": (C.c_int, [_VP, C.c_int]),
     "od_ilqr_al_update": (C.c_int, [_VP]),

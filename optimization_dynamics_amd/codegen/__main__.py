@@ -38,8 +38,20 @@ def main(argv):
     ap.add_argument("names", nargs="*", help="models to regenerate (default: all registered)")
     ap.add_argument("--add", action="append", default=[], metavar="SPEC.py", help="register and generate a new model (defines spec() -> ModelSpec)")
     ap.add_argument("--root", default=DEFAULT_ROOT, help="repository root to write into (default: this checkout)")
+    ap.add_argument("--add-constraint", action="append", default=[], metavar="SPEC.py",
+                    help="register and generate a nonlinear constraint function for the device-resident iLQR solver (defines constraint() -> ConstraintSpec; codegen/constraints.py)")
+    ap.add_argument("--constraints", action="store_true", help="regenerate the constraint functions only")
     args = ap.parse_args(argv[1:])
     root = os.path.abspath(args.root)
+    if args.add_constraint or args.constraints:
+        from . import constraints as CN
+        cud = os.path.join(root, "optimization_dynamics_amd", "codegen", "user_models")
+        new = [CN.register(pth, cud) for pth in args.add_constraint]
+        order = CN.generate(root)
+        if new:
+            print("registered constraint(s): %s (ids %s).  Rebuild: make -C optimization_dynamics_amd/csrc" % (", ".join(new), ", ".join(str(order.index(n)) for n in new)))
+        if not args.names and not args.add:
+            return
     udir = os.path.join(root, "optimization_dynamics_amd", "codegen", "user_models")
     dev_dir = os.path.join(root, "optimization_dynamics_amd", "csrc", "gen")
     csrc = os.path.dirname(dev_dir)

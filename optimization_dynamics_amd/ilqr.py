@@ -43,9 +43,19 @@ class QuadraticObjective:
         self.terminal = None if terminal is None else (f(terminal[0]).reshape(-1, self.n), f(terminal[1]).reshape(-1), int(terminal[2]))
         return self
 
+    def set_parameter_stage(self, w_theta, constraint=None, p=None, terminal=None, cost_const=0.0):
+        """od_ilqr_set_parameter_stage (examples/hopper.jl: the initial configurations theta = [q1; q2] optimised with the controls):
+        slot 0 of every trajectory is theta, costing 1/2 theta' diag(w_theta) theta + cost_const; `constraint`: name of a generated
+        constraint function c(theta; p) = 0 (codegen --add-constraint); terminal = (Ct_x (nt, n), Ct_theta (nt, n), dt (nt,), n_ineq):
+        rows Ct_x x_T + Ct_theta theta - dt.  Device-resident solver only (ILQR.solve)."""
+        f = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+        self.parameter_stage = dict(w_theta=f(w_theta), constraint=constraint, p=None if p is None else f(p), cost_const=float(cost_const),
+                                    terminal=None if terminal is None else (f(terminal[0]).reshape(-1, self.n), f(terminal[1]).reshape(-1, self.n), f(terminal[2]).reshape(-1), int(terminal[3])))
+        return self
+
     @property
     def constrained(self):
-        return self.goal_idx is not None or self.stage is not None or self.terminal is not None
+        return self.goal_idx is not None or self.stage is not None or self.terminal is not None or getattr(self, "parameter_stage", None) is not None
 
     # the constraint rows, evaluated in the order of the device kernels (od_ilqr_solver.inc: sum over x then over u, then - d)
     def stage_c(self, X, U):
@@ -514,6 +524,24 @@ class DeviceILQR:
             q = lambda a: None if a is None else dp(a)
             self._keep = (Cs, Ds, ds, Ct, dt)
             self.lib.check(self.lib.cdll.od_ilqr_set_constraints(self._s, ns, nsi, q(Cs), q(Ds), q(ds), nt, nti, q(Ct), q(dt)))
+        ps = getattr(obj, "parameter_stage", None)
+        if ps is not None:
+            q = _lib.IlqrParameterStage()
+            cid = -1
+            if ps["constraint"] is not None:
+                cid = self.lib.cdll.od_constraint_id(ps["constraint"].encode())
+                if cid < 0:
+                    raise _lib.ODError("constraint function %r is not in this library (python -m optimization_dynamics_amd.codegen --add-constraint)" % ps["constraint"])
+            cm = lambda M: np.ascontiguousarray(M.T).reshape(-1)
+            keep = [ps["w_theta"], ps["p"]]
+            q.constraint, q.n_p, q.p = cid, (0 if ps["p"] is None else ps["p"].size), (None if ps["p"] is None else dp(ps["p"]))
+            q.w_theta, q.cost_const = dp(ps["w_theta"]), ps["cost_const"]
+            if ps["terminal"] is not None:
+                cx, cth, dtt, ni = ps["terminal"]
+                keep += [cm(cx), cm(cth), dtt]
+                q.nt, q.nt_ineq, q.Ct_x, q.Ct_theta, q.dt = dtt.size, ni, dp(keep[-3]), dp(keep[-2]), dp(keep[-1])
+            self._keep_ps = keep
+            self.lib.check(self.lib.cdll.od_ilqr_set_parameter_stage(self._s, C.byref(q)))
         self.max_hist = history if history > 0 else max_iter * max_al_iter
 
     def __del__(self):

@@ -334,3 +334,242 @@ def rocket_dynamics(h=0.05, u_max=12.5, project=True):
         return Xr[:, :, 0].T.copy(), Ua[:, :, 0].T.copy(), bool((st == 0x11).all())
 
     return step, linearise, roll
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The same augmented-Lagrangian iLQR for stages of DIFFERENT dimensions, general stage costs and general (nonlinear) constraints -- what
+# iLQR.solver(model, obj, cons) of IterativeLQR.jl accepts and examples/hopper.jl uses (a first stage R^8 x R^10 -> R^16, then
+# R^16 x R^2 -> R^16; nonlinear foot-position constraints at the first stage, a terminal constraint that couples the last state with
+# the initial configurations carried along in it): the independent checker of od_ilqr_* with a parameter stage
+# (od_ilqr_set_parameter_stage).  Same rules as `solve` above; the stages are given as callables.
+class Stage:
+    """one stage t < T:  step(x, u) -> (converged, y);  jac(x, u) -> (A (ny, nx), B (ny, nu));
+    cost(x, u) -> (l, lx, lu, lxx, luu, lux);  con(x, u) -> (c, cx, cu) or None, the leading n_ineq rows inequalities (<= 0)"""
+
+    def __init__(self, step, jac, cost, con=None, n_ineq=0):
+        self.step, self.jac, self.cost, self.con, self.n_ineq = step, jac, cost, con, n_ineq
+
+
+def solve_stages(stages, terminal_cost, terminal_con, nt_ineq, x1, U0, alphas=tuple(2.0 ** -i for i in range(11)), reg0=1e-6, c1=1e-4,
+                 obj_tol=1e-6, con_tol=1e-3, rho_init=1.0, rho_scale=10.0, rho_max=1e8, max_iter=50, max_al_iter=1):
+    """stages: list of T Stage objects; terminal_cost(x) -> (l, lx, lxx); terminal_con(x) -> (c, cx) or None; U0: list of T control
+    vectors.  -> dict(X (list), U (list), J, objective, violation, al_done, done, log)"""
+    T = len(stages)
+
+    def roll(Ubar, policy=None):
+        X, U, ok = [np.asarray(x1, float)], [], True
+        for t in range(T):
+            u = Ubar[t] if policy is None else Ubar[t] + policy[0] * policy[3][t] + policy[2][t] @ (X[t] - policy[1][t])
+            o, y = stages[t].step(X[t], u)
+            ok = ok and bool(o)
+            U.append(u); X.append(y)
+        return X, U, ok
+
+    def cons(X, U):
+        """per stage (c, cx, cu) or None; terminal (c, cx) or None"""
+        cs = [st.con(X[t], U[t]) if st.con is not None else None for t, st in enumerate(stages)]
+        ct = terminal_con(X[T]) if terminal_con is not None else None
+        return cs, ct
+
+    constrained = terminal_con is not None or any(st.con is not None for st in stages)
+    X, U, _ = roll([np.asarray(u, float) for u in U0])
+    cs, ct = cons(X, U)
+    lam_s = [None if c is None else np.zeros(c[0].size) for c in cs]
+    lam_t = None if ct is None else np.zeros(ct[0].size)
+    rho = rho_init if constrained else 0.0
+
+    def merit(X, U, with_mult=True):
+        J = sum(stages[t].cost(X[t], U[t])[0] for t in range(T)) + terminal_cost(X[T])[0]
+        if not with_mult or not constrained:
+            return float(J)
+        cs, ct = cons(X, U)
+        for t, c in enumerate(cs):
+            if c is not None:
+                a = _active(c[0], lam_s[t], stages[t].n_ineq)
+                J += lam_s[t] @ c[0] + 0.5 * rho * (c[0][a] ** 2).sum()
+        if ct is not None:
+            a = _active(ct[0], lam_t, nt_ineq)
+            J += lam_t @ ct[0] + 0.5 * rho * (ct[0][a] ** 2).sum()
+        return float(J)
+
+    def viol(X, U):
+        cs, ct = cons(X, U)
+        v = 0.0
+        for t, c in enumerate(cs):
+            if c is not None:
+                k = stages[t].n_ineq
+                v = max(v, np.maximum(c[0][:k], 0.0).max(initial=0.0), np.abs(c[0][k:]).max(initial=0.0))
+        if ct is not None:
+            v = max(v, np.maximum(ct[0][:nt_ineq], 0.0).max(initial=0.0), np.abs(ct[0][nt_ineq:]).max(initial=0.0))
+        return float(v)
+
+    def backward(AB, reg):
+        cs, ct = cons(X, U)
+        l, Vx, Vxx = terminal_cost(X[T])
+        Vx, Vxx = Vx.copy(), Vxx.copy()
+        if ct is not None:
+            ra = np.where(_active(ct[0], lam_t, nt_ineq), rho, 0.0)
+            Vx = Vx + ct[1].T @ (lam_t + ra * ct[0]); Vxx = Vxx + ct[1].T @ (ra[:, None] * ct[1])
+        K, k, dV = [None] * T, [None] * T, np.zeros(2)
+        for t in range(T - 1, -1, -1):
+            A, Bm = AB[t]
+            _, lx, lu, lxx, luu, lux = stages[t].cost(X[t], U[t])
+            if cs[t] is not None:
+                c, cx, cu = cs[t]
+                ra = np.where(_active(c, lam_s[t], stages[t].n_ineq), rho, 0.0)
+                w = lam_s[t] + ra * c
+                lx = lx + cx.T @ w; lu = lu + cu.T @ w
+                lxx = lxx + cx.T @ (ra[:, None] * cx); luu = luu + cu.T @ (ra[:, None] * cu); lux = lux + cu.T @ (ra[:, None] * cx)
+            Qx = lx + A.T @ Vx; Qu = lu + Bm.T @ Vx
+            Qxx = lxx + A.T @ Vxx @ A; Quu = luu + Bm.T @ Vxx @ Bm; Qux = lux + Bm.T @ Vxx @ A
+            Qr = Quu + reg * np.eye(Quu.shape[0])
+            try:
+                if not np.isfinite(Qr).all():
+                    return None
+                np.linalg.cholesky(0.5 * (Qr + Qr.T))
+            except np.linalg.LinAlgError:
+                return None
+            K[t] = -np.linalg.solve(Qr, Qux); k[t] = -np.linalg.solve(Qr, Qu)
+            dV += [k[t] @ Qu, 0.5 * k[t] @ Quu @ k[t]]
+            Vx = Qx + K[t].T @ Quu @ k[t] + K[t].T @ Qu + Qux.T @ k[t]
+            Vxx = Qxx + K[t].T @ Quu @ K[t] + K[t].T @ Qux + Qux.T @ K[t]
+            Vxx = 0.5 * (Vxx + Vxx.T)
+        return K, k, dV
+
+    reg, done, al_done, log, v = reg0, False, False, [], 0.0
+    AB = [stages[t].jac(X[t], U[t]) for t in range(T)]
+    for al in range(max_al_iter):
+        J = merit(X, U)
+        for it in range(max_iter):
+            if done:
+                break
+            r, res = reg, None
+            while True:
+                res = backward(AB, r)
+                if res is not None or r >= 1e6:
+                    break
+                r = min(max(r, 1e-8) * 10.0, 1e6)
+            step, Jn, cand = -1, J, None
+            if res is not None:
+                K, k, dV = res
+                for ia, a in enumerate(alphas):
+                    Xc, Uc, okc = roll(U, (a, X, K, k))
+                    Jc = merit(Xc, Uc)
+                    if okc and np.isfinite(Jc) and Jc <= J + c1 * (a * dV[0] + a * a * dV[1]):
+                        step, Jn, cand = ia, Jc, (Xc, Uc)
+                        break
+            dJ = J - Jn
+            if step >= 0:
+                X, U = cand
+                J = Jn
+                AB = [stages[t].jac(X[t], U[t]) for t in range(T)]
+                reg = max(reg / 5.0, reg0)
+                done = dJ < obj_tol
+            else:
+                reg = min(reg * 10.0, 1e6)
+                done = reg >= 1e6
+            log.append(dict(al=al, step=step, reg=reg, rho=rho, J=J, dJ=dJ, reg_used=r))
+        if not constrained:
+            break
+        v = viol(X, U)
+        if v < con_tol:
+            al_done, done = True, True
+            break
+        if al + 1 == max_al_iter:
+            break
+        cs, ct = cons(X, U)
+        for t, c in enumerate(cs):
+            if c is not None:
+                l = lam_s[t] + rho * c[0]; kk = stages[t].n_ineq
+                l[:kk] = np.where(l[:kk] > 0.0, l[:kk], 0.0)
+                lam_s[t] = l
+        if ct is not None:
+            l = lam_t + rho * ct[0]
+            l[:nt_ineq] = np.where(l[:nt_ineq] > 0.0, l[:nt_ineq], 0.0)
+            lam_t = l
+        rho = min(rho * rho_scale, rho_max)
+        reg, done = reg0, False
+    return dict(X=X, U=U, J=J, objective=merit(X, U, False), violation=v, al_done=al_done, done=done, log=log, rho=rho, reg=reg)
+
+
+def hopper_gait_stages(sim, h=0.05, T=20, foot_radius=0.05, r_cost=0.1, q_cost=0.1):
+    """examples/hopper.jl as shipped (GAIT 1): stage 1 R^8 x R^10 -> R^16 (f1 / f1x / f1u :52-101: the controls carry the initial
+    configurations theta = [q1; q2]), stages t >= 2 R^16 x R^2 -> R^16 (ft / ftx / ftu :103-160), obj1 / objt / objT :207-226,
+    stage1_con / staget_con / terminal_con :234-266.  -> (stages, terminal_cost, terminal_con, nt_ineq, x1, U0)"""
+    from . import oracle as O
+    nq, nu = 4, 2
+    q1 = np.array([0.0, 0.5 + foot_radius, 0.0, 0.5]); q_ref = np.array([0.5, 0.75 + foot_radius, 0.0, 0.25])
+    x1 = np.concatenate([q1, q1]); x_ref = np.concatenate([q_ref, q_ref])
+    w = np.array([1.0, 10.0, 1.0, 10.0] * 2)
+    foot = lambda q: np.array([q[0] + q[3] * np.sin(q[2]), q[1] - q[3] * np.cos(q[2])])
+    dfoot = lambda q: np.array([[1.0, 0.0, q[3] * np.cos(q[2]), np.sin(q[2])], [0.0, 1.0, q[3] * np.sin(q[2]), -np.cos(q[2])]])
+
+    def step8(x8, u2):
+        ok, d, it = O.f(sim, x8, u2)
+        return ok, d
+
+    def jac8(x8, u2):
+        return O.fx(sim, x8, u2)[1], O.fu(sim, x8, u2)[1]
+
+    def f1(x, u):
+        ok, d = step8(u[nu:nu + 8], u[:nu])
+        return ok, np.concatenate([d, u[nu:nu + 8]])
+
+    def f1jac(x, u):
+        A8, B8 = jac8(u[nu:nu + 8], u[:nu])
+        A = np.zeros((16, 8)); Bm = np.zeros((16, 10))
+        Bm[:8, :nu] = B8; Bm[:8, nu:] = A8; Bm[8:, nu:] = np.eye(8)
+        return A, Bm
+
+    def ft(x, u):
+        ok, d = step8(x[:8], u)
+        return ok, np.concatenate([d, x[8:]])
+
+    def ftjac(x, u):
+        A8, B8 = jac8(x[:8], u)
+        A = np.zeros((16, 16)); A[:8, :8] = A8; A[8:, 8:] = np.eye(8)
+        Bm = np.zeros((16, 2)); Bm[:8] = B8
+        return A, Bm
+
+    R1 = np.concatenate([r_cost * np.ones(nu), 1.0e-1 * np.ones(nq), 1.0e-5 * np.ones(nq)])
+
+    def obj1(x, u):
+        dx = x - x_ref
+        return (0.5 * dx @ (w * dx) + 0.5 * u @ (R1 * u), w * dx, R1 * u, np.diag(w), np.diag(R1), np.zeros((10, 8)))
+
+    wt = np.concatenate([q_cost * w, np.zeros(8)]); xr16 = np.concatenate([x_ref, np.zeros(8)])
+
+    def objt(x, u):
+        dx = x - xr16
+        return (0.5 * dx @ (wt * dx) + 0.5 * r_cost * u @ u, wt * dx, r_cost * u, np.diag(wt), r_cost * np.eye(2), np.zeros((2, 16)))
+
+    wT = np.concatenate([np.ones(8), np.zeros(8)])
+
+    def objT(x):
+        dx = x - xr16
+        return 0.5 * dx @ (wT * dx), wT * dx, np.diag(wT)
+
+    def con1(x, u):
+        qa, qb = u[nu:nu + nq], u[nu + nq:nu + 2 * nq]
+        c = np.concatenate([-10.0 - u[:nu], u[:nu] - 10.0, qa - x1[:nq], foot(qa) - foot(x1[:nq]), foot(qb) - foot(x1[nq:])])
+        cu = np.zeros((12, 10))
+        cu[0:2, 0:2] = -np.eye(2); cu[2:4, 0:2] = np.eye(2); cu[4:8, 2:6] = np.eye(4); cu[8:10, 2:6] = dfoot(qa); cu[10:12, 6:10] = dfoot(qb)
+        return c, np.zeros((12, 8)), cu
+
+    def cont(x, u):
+        return np.concatenate([-10.0 - u, u - 10.0]), np.zeros((4, 16)), np.vstack([-np.eye(2), np.eye(2)])
+
+    def conT(x):
+        th = x[8:]
+        c = np.concatenate([[0.5 - (x[0] - th[0]), 0.5 - (x[4] - th[4])], x[[1, 2, 3]] - th[[1, 2, 3]], x[[5, 6, 7]] - th[[5, 6, 7]]])
+        cx = np.zeros((8, 16))
+        cx[0, 0], cx[0, 8] = -1.0, 1.0
+        cx[1, 4], cx[1, 12] = -1.0, 1.0
+        for k, i in enumerate([1, 2, 3, 5, 6, 7]):
+            cx[2 + k, i], cx[2 + k, 8 + i] = 1.0, -1.0
+        return c, cx
+
+    stages = [Stage(f1, f1jac, obj1, con1, 4)] + [Stage(ft, ftjac, objt, cont, 4) for _ in range(T - 1)]
+    ustand = np.array([0.0, 9.81 * 3.0 * 0.5 * h])
+    U0 = [np.concatenate([ustand, x1])] + [ustand.copy() for _ in range(T - 1)]
+    return stages, objT, conT, 2, x1, U0

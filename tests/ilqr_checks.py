@@ -771,3 +771,90 @@ def check_against_numpy_oracle(oracle, lib, device, case, B=8, seed=1):
             assert 0.4 * abs(Jo) <= abs(Jd) <= 2.5 * abs(Jo), (case, b, Jd, Jo)
             assert abs(len(L) - len(rows)) <= max(3, 0.5 * len(L)), (case, b, len(L), len(rows))
     return stats
+
+
+# ---- examples/hopper.jl AS SHIPPED (the initial configurations optimised through a first stage of its own dimensions) on the device ------
+def hopper_example_full(lib, device, B, seed=1):
+    """examples/hopper.jl:12-13,42-50,176-290, GAIT 1: T = 21, h = 0.05; u_1 = [u; theta] with theta = [q1; q2] the two initial
+    configurations (od_ilqr_set_parameter_stage: slot 0 of the trajectory), obj1 / objt / objT (:207-226), stage1_con (control limits,
+    q1 fixed, foot positions: the generated `hopper_foot`), staget_con (control limits), terminal_con (:256-262, couples x_T with theta).
+    Problem 0 starts from the standing controls (:270), the others from perturbed ones."""
+    HP = dict(foot_radius=0.05, gravity=9.81, mass_body=3.0)
+    h, T = 0.05, 20
+    im = P.make_im("hopper", lib, device)
+    r = HP["foot_radius"]
+    q1 = np.array([0.0, 0.5 + r, 0.0, 0.5]); q_ref = np.array([0.5, 0.75 + r, 0.0, 0.25])
+    x1v, x_ref = np.concatenate([q1, q1]), np.concatenate([q_ref, q_ref])
+    w = np.array([1.0, 10.0, 1.0, 10.0] * 2)
+    obj = IL.QuadraticObjective(0.1 * np.diag(w), 0.1 * np.eye(2), np.eye(8), x_ref=x_ref, device=device)
+    Cs = np.zeros((4, 8)); Ds = np.vstack([-np.eye(2), np.eye(2)]); ds = np.full(4, 10.0)
+    obj.set_constraints(stage=(Cs, Ds, ds, 4))
+    Ctx = np.zeros((8, 8)); Cth = np.zeros((8, 8)); dt = np.zeros(8)
+    Ctx[0, 0], Cth[0, 0], dt[0] = -1.0, 1.0, -0.5             # x_travel - (x[1] - theta[1]) <= 0
+    Ctx[1, 4], Cth[1, 4], dt[1] = -1.0, 1.0, -0.5
+    for k, i in enumerate([1, 2, 3, 5, 6, 7]):
+        Ctx[2 + k, i], Cth[2 + k, i] = 1.0, -1.0
+    w_theta = np.array([1.0e-1] * 4 + [1.0e-5] * 4)              # obj1's weights on u[3:10] (:209)
+    c0 = 0.5 * float((x1v - x_ref) @ (w * (x1v - x_ref)))        # obj1's cost of the fixed x_1
+    obj.set_parameter_stage(w_theta, constraint="hopper_foot", p=x1v, terminal=(Ctx, Cth, dt, 2), cost_const=c0)
+    U0 = np.zeros((2, T, B)); U0[1] = HP["gravity"] * HP["mass_body"] * 0.5 * h
+    U0[:, :, 1:] += 1e-2 * np.random.default_rng(seed).normal(size=(2, T, B - 1))
+    x1 = np.repeat(x1v[:, None], B, axis=1)
+    opts = dict(max_iter=10, max_al_iter=15, con_tol=1.0e-3, obj_tol=1.0e-3, rho_init=1.0, rho_scale=10.0)
+    return im, obj, x1, U0, x1v, T, opts
+
+
+def check_hopper_example_full(oracle, lib, device, B=1, n_oracle=1):
+    """examples/hopper.jl as shipped through od_ilqr_solve -- parameter stage, generated nonlinear constraint, coupled terminal rows --
+    against oracle/ilqr_np.py::solve_stages on the reference's own formulation (stages of dimensions 8 / 10 -> 16 and 16 / 2 -> 16,
+    constraint functions as the example writes them) with the oracle's dynamics: the decisions of every iteration on the first
+    `n_oracle` problems (accepted step index, regularisation, penalty, merit), the optimised initial configurations, the
+    constraints to con_tol on every problem"""
+    from oracle import ilqr_np as N
+    im, obj, x1, U0, x1v, T, opts = hopper_example_full(lib, device, B)
+    alphas = tuple(2.0 ** -i for i in range(17))
+    sol = IL.ILQR(im, obj, T, alphas=alphas)
+    X, U, J, hist = sol.solve(torch.tensor(x1, device=device), torch.tensor(U0, device=device), **opts)
+    d = sol._dev
+    info = d.info()
+    fl, viol, rho = [a.cpu().numpy() for a in d.status()]
+    sel, reg, rh = [a.cpu().numpy() for a in d.trace()]
+    H = torch.stack(hist).cpu().numpy()
+    Xn, Un = X.cpu().numpy(), U.cpu().numpy()
+    assert (viol < opts["con_tol"]).all() and ((fl & 2) != 0).all(), (viol.max(), fl)
+    assert (np.abs(Un) <= 10.0 + opts["con_tol"]).all()
+    th, xT = Xn[:, 0], Xn[:, -1]
+    assert (xT[0] - th[0] >= 0.5 - 1e-3).all() and (xT[4] - th[4] >= 0.5 - 1e-3).all()          # half a metre further ...
+    keep = [1, 2, 3, 5, 6, 7]
+    assert np.abs(xT[keep] - th[keep]).max() < 1e-3                                              # ... in the pose the gait started from
+    foot = lambda q: np.array([q[0] + q[3] * np.sin(q[2]), q[1] - q[3] * np.cos(q[2])])
+    assert np.abs(th[:4] - x1v[:4, None]).max() < 1e-3 and np.abs(foot(th[4:8]) - foot(x1v[4:8])[:, None]).max() < 1e-3
+    assert np.abs(th[4:8] - x1v[4:8, None]).max() > 1e-2, "the second initial configuration was not optimised"
+    # the returned trajectory is the rollout of its controls from its theta
+    Xr = im.rollout(X[:, 0].contiguous(), U, grads=False)[0]
+    assert (Xr - X).abs().max().item() < 1e-9
+    stats = dict(problems=B, iterations=int(info.iterations), rounds=int(info.al_iterations), violation_max=float(viol.max()),
+                 objective=[float(v) for v in J[: min(B, 4)].cpu().numpy()], agreeing_iterations=[], iterations_oracle=[])
+    sim = oracle.make_sim("hopper", 0.05, kappa_tol=1e-4, kappa_grad_tol=1e-3, friction=[0.5, 0.5])
+    for b in range(min(B, n_oracle)):
+        st, objT, conT, nti, x1o, U0o = N.hopper_gait_stages(sim)
+        U0o = [np.concatenate([U0[:, 0, b], x1v])] + [U0[:, t, b] for t in range(1, T)]
+        r = N.solve_stages(st, objT, conT, nti, x1o, U0o, alphas=alphas, reg0=sol.reg, c1=sol.c1, **{k: v for k, v in opts.items()})
+        L = r["log"]
+        rows = [i for i in range(sel.shape[0]) if sel[i, b] != -2]
+        nag = 0
+        for l, i in zip(L, rows):
+            same = l["step"] == sel[i, b] and abs(l["reg"] - reg[i, b]) <= 1e-12 * reg[i, b] and abs(l["rho"] - rh[i, b]) <= 1e-12 * max(1.0, rh[i, b])
+            if not (same and abs(l["J"] - H[i, b]) <= 1e-7 * max(1.0, abs(l["J"]))):
+                break
+            nag += 1
+        stats["agreeing_iterations"].append(nag); stats["iterations_oracle"].append(len(L))
+        # (a hopping gait switches contact modes: the 1e-12 between two implementations of one step can grow, see ORACLE_CASES)
+        assert nag >= min(10, len(L)), (b, nag, len(L), len(rows))
+        assert r["al_done"] and abs(len(L) - len(rows)) <= max(3, len(L) // 4), (len(L), len(rows))
+        assert abs(r["J"] - float(J[b].item())) <= (1e-6 if nag == len(L) == len(rows) else 5e-2) * abs(r["J"]), (r["J"], float(J[b].item()))       # (the merit: J carries the multiplier terms)
+        th_o = r["U"][0][2:]
+        assert np.abs(th_o - th[:, b]).max() < 5e-2, (th_o, th[:, b])
+        stats["theta_device"] = [float(v) for v in th[:, b]]; stats["theta_oracle"] = [float(v) for v in th_o]
+        stats["objective_oracle"] = float(r["objective"])
+    return stats

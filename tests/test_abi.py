@@ -100,7 +100,8 @@ def _null_fuzz(emu_lib, device):
     import parity_checks as P
     cd = emu_lib.cdll
     queries = {"od_version", "od_num_models", "od_model_name", "od_last_error", "od_model_indices", "od_model_dims",
-               "od_raw_grad_dims", "od_uses_cooperative", "od_bundle_workspace_bytes", "od_destroy", "od_ilqr_destroy"}
+               "od_raw_grad_dims", "od_uses_cooperative", "od_bundle_workspace_bytes", "od_destroy", "od_ilqr_destroy",
+               "od_num_constraints", "od_constraint_name", "od_constraint_dims"}
     for name in sorted(_lib.SIGNATURES):
         fn = getattr(cd, name)
         r = fn(*_zero_args(fn))

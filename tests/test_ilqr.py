@@ -212,3 +212,60 @@ def test_solver_decisions_against_the_numpy_oracle_gpu(oracle, gpu_lib):
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(d, exist_ok=True)
     json.dump(out, open(os.path.join(d, "ilqr_oracle_parity.json"), "w"), indent=1)
+
+
+# ---- examples/hopper.jl as shipped: parameter stage (initial configurations optimised), generated nonlinear constraint ------------------------
+def test_hopper_example_full_on_the_device_cpu(oracle, emu_lib):
+    """host build of the product sources: one problem, every decision against the numpy oracle on the reference's own formulation"""
+    st = C.check_hopper_example_full(oracle, emu_lib, "cpu", B=1, n_oracle=1)
+    assert st["agreeing_iterations"][0] == st["iterations_oracle"][0] == st["iterations"]
+
+
+@pytest.mark.gpu
+def test_hopper_example_full_on_the_device_gpu(oracle, gpu_lib):
+    """examples/hopper.jl as shipped -- the first stage of its own dimensions (8 -> 16 states, 10 controls), nonlinear foot-position
+    constraints, the terminal constraint coupled with the optimised initial configurations -- through od_ilqr_solve with no host
+    synchronisation per iteration: 64 problems, the first four against the numpy oracle decision by decision"""
+    import json
+    import os
+    st = C.check_hopper_example_full(oracle, gpu_lib, "cuda:0", B=64, n_oracle=4)
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    json.dump(st, open(os.path.join(d, "hopper_example_full.json"), "w"), indent=1)
+    assert 25 <= st["iterations"] <= 60
+
+
+def test_constraint_generator_builds_a_new_constraint(tmp_path):
+    """python -m optimization_dynamics_amd.codegen --add-constraint: a user's sympy constraint becomes device code (into a scratch root)"""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = tmp_path / "circle.py"
+    spec.write_text("from optimization_dynamics_amd.codegen.constraints import ConstraintSpec\n"
+                    "def constraint():\n"
+                    "    return ConstraintSpec('unit_circle', 8, 1, lambda x, p: [x[0]**2 + x[1]**2 - p[0]**2, x[4] - x[0]], 'test')\n")
+    scratch = tmp_path / "root"
+    (scratch / "optimization_dynamics_amd" / "csrc" / "gen").mkdir(parents=True)
+    (scratch / "optimization_dynamics_amd" / "codegen" / "user_models").mkdir(parents=True)
+    out = subprocess.run([sys.executable, "-m", "optimization_dynamics_amd.codegen", "--add-constraint", str(spec), "--root", str(scratch)],
+                         cwd=root, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    hdr = (scratch / "optimization_dynamics_amd" / "csrc" / "gen" / "con_unit_circle.h").read_text()
+    assert "struct Con_unit_circle" in hdr and "NC = 2, NX = 8, NP = 1" in hdr
+    lst = (scratch / "optimization_dynamics_amd" / "csrc" / "gen" / "con_list.h").read_text()
+    assert "X(hopper_foot, 0)" in lst and "X(unit_circle, 1)" in lst
+    # the generated code compiles and evaluates: c and dc/dx against numpy (the header includes "../od_math.h" like every generated header)
+    import shutil
+    shutil.copy(os.path.join(root, "optimization_dynamics_amd", "csrc", "od_math.h"), scratch / "optimization_dynamics_amd" / "csrc" / "od_math.h")
+    src = tmp_path / "t.cpp"
+    src.write_text('#include <cstdio>\n#include <hip/hip_runtime.h>\n#include "gen/con_unit_circle.h"\n'
+                   'int main() { double x[8] = {0.6, 0.9, 0, 0, 0.1, 0, 0, 0}, p[1] = {1.5}, c[2], cx[16];\n'
+                   '  od::Con_unit_circle::eval<double>(x, p, c, cx); printf("%.17g %.17g %.17g %.17g %.17g %.17g\\n", c[0], c[1], cx[0], cx[2], cx[1], cx[9]); }\n')
+    exe = tmp_path / "t"
+    cc = subprocess.run(["g++", "-std=c++17", "-I", os.path.join(root, "tests", "host_emu"), "-I", os.path.join(root, "optimization_dynamics_amd", "csrc"),
+                         "-I", str(scratch / "optimization_dynamics_amd" / "csrc"), str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    v = [float(t) for t in subprocess.run([str(exe)], capture_output=True, text=True).stdout.split()]
+    assert abs(v[0] - (0.36 + 0.81 - 2.25)) < 1e-15 and abs(v[1] - (0.1 - 0.6)) < 1e-15
+    assert abs(v[2] - 1.2) < 1e-15 and abs(v[3] - 1.8) < 1e-15 and v[4] == -1.0 and v[5] == 1.0
