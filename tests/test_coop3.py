@@ -232,3 +232,14 @@ def test_parallel_line_search_variant_emulated(emu_lib):
         for a, b in zip(*out):
             if torch.is_tensor(a):
                 assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [3, 2])
+def test_policy_rollout_with_converged_trajectories_gpu(gpu_lib, mode):
+    """the device-resident solver on the hopper under the 8-lane (mode 3) and the 16-lane (mode 2) cooperative rollout kernels, seven
+    problems that converge at different iterations: each equals its solve in a batch of one bit for bit, so a group whose DPP-row
+    partner has left computes what it computes beside a live partner"""
+    import ilqr_checks as C
+    its = C.check_converged_neighbours_do_not_disturb(gpu_lib, "cuda:0", mode)
+    print("iterations per problem:", its)
