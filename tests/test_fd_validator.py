@@ -67,7 +67,7 @@ def test_direct_method_against_ilqr_on_the_hopper_gait(oracle):
     feasible, its objective within a few per cent of the iLQR solution's -- it may not be beaten by much by a method that is handed the
     iLQR answer as a start --, and its controls drive the time-stepping simulator along the same motion."""
     from oracle import direct_validator as D
-    r = D.compare()
+    r = D.compare(maxiter=400)
     print("hopper gait: iLQR J = %.4f (violation %.1e, %d iterations); direct J = %.4f (equality rows %.1e, slack max %.1e, %d iterations, optimality %.1e)"
           % (r["ilqr_objective"], r["ilqr_violation"], r["ilqr_iterations"], r["direct_objective"], r["direct_equality_violation"], r["direct_slack_max"],
              r["direct_iterations"], r["direct_optimality"]))
