@@ -952,17 +952,17 @@ def check_rocket_sweep(oracle, lib, device, B, seed, dtype=torch.float64, u_max=
     conv_d, conv_o = (stp & 0x30) == 0x30, stpo == 1
     both = conv_d & conv_o
     TH = np.vstack([U, np.full((1, B), u_max)])
-    # status bits: a solve that converges in the oracle in fewer than 30 iterations is not a stalled one -- the device must converge too
-    # (and the other way round); the stalled population (accepted steps ~1e-13 for ~85 iterations, then max_iter or a late escape by
-    # rounding drift) is reported by both as it ends for each: its size and the disagreements are recorded and bounded
+    # status bits.  A solve that converges in fewer than 30 iterations in BOTH implementations is an ordinary one: there the status bits
+    # agree by construction of the comparison (both converged).  The rest is the stalled population (the iterate runs into
+    # the boundary of the cone, accepted steps ~1e-13 for ~85 iterations, then max_iter or a late escape by rounding drift): whether a
+    # control enters it, and how it leaves, is decided at rounding level, so one implementation may be through in 12 iterations where
+    # the other stalls (seen once per 8192 controls on other seeds).  Its size and the disagreements inside it are bounded and recorded.
     plain_o, plain_d = conv_o & (itpo < 30), conv_d & (itp < 30)
-    stalled = ~(plain_o | plain_d)
-    # (single precision: the float solve stops at r_tol = 1e-4 where the double one asks for 1e-8 -- a handful of solves near the apex
-    # that stall in double are through in float, and the other way round)
-    lim = 0 if f64 else max(2, B // 500)
-    assert (plain_o & ~conv_d).sum() <= lim, (row["dtype"], "not stalled in the oracle, not converged on the device", int((plain_o & ~conv_d).sum()))
-    assert (plain_d & ~conv_o).sum() <= lim, (row["dtype"], "converged on the device in < 30 iterations, not in the oracle", int((plain_d & ~conv_o).sum()))
-    assert stalled.sum() <= max(4, B // 100), int(stalled.sum())
+    stalled = ~(plain_o & plain_d)
+    assert stalled.sum() <= max(4, B // 100), (row["dtype"], int(stalled.sum()))
+    ndis = int((conv_d != conv_o).sum())
+    # (single precision: the float solve stops at r_tol = 1e-4 where the double one asks for 1e-8 -- a few more disagreements near the apex)
+    assert ndis <= (max(3, B // 1000) if f64 else max(4, B // 250)), (row["dtype"], "status disagreements", ndis)
     Ed, cond = oracle.arbiter_gradient_batch("rocket_projection", Z, TH)
     Eo, _ = oracle.arbiter_gradient_batch("rocket_projection", Zo, TH)
     Ed, Eo, Go = Ed[:3, :3], Eo[:3, :3], DPo[:3, :3]
@@ -1032,11 +1032,14 @@ def check_rocket_sweep(oracle, lib, device, B, seed, dtype=torch.float64, u_max=
     chain = np.einsum("ikb,kcb->icb", DZo2[:, 12:15], DP)
     eu = rel(DU, chain, 0)
     # (single precision: od_rocket's own float projection gradient and od_soc_project_full's are two compilations of a float
-    # factorisation -- each within the knot's conditioning bound of (2) of the exact gradient, so up to twice that apart)
+    # factorisation; they are comparable where both kernels stopped at the SAME float iterate -- bit-equal projected control, nine
+    # knots in ten --, and there each is within the knot's conditioning bound of (2) of the exact gradient at that iterate)
     amp = np.abs(DZo2[:, 12:15]).reshape(-1, B).max(0) * sc / np.maximum(1.0, np.abs(chain).reshape(-1, B).max(0))
-    tol_u = GRAD_TOL + (0.0 if f64 else 1.0) * 8.0 * np.where(np.isfinite(bound), bound, 0.0) * amp
-    assert (eu[same] <= tol_u[same]).all(), float((eu[same] / tol_u[same]).max())
-    eu = eu[same]
+    tol_u = GRAD_TOL + (0.0 if f64 else 1.0) * 4.0 * np.where(np.isfinite(bound), bound, 0.0) * amp
+    cmp_u = same if f64 else same & (UP == Z[:3]).all(0)
+    assert cmp_u.sum() >= 0.85 * okc.sum(), (int(cmp_u.sum()), int(okc.sum()))
+    assert (eu[cmp_u] <= tol_u[cmp_u]).all(), (row["dtype"], "chain product fu", float((eu[cmp_u] / tol_u[cmp_u]).max()))
+    eu = eu[cmp_u]
     row.update(chain_converged=int(okc.sum()), chain_state_rel_max=float(es.max()), chain_fx_rel_max=float(ex.max()), chain_fu_rel_max=float(eu.max()),
                chain_same_projection_in_both_kernels=int(same.sum()))
     return row
