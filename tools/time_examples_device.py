@@ -1,6 +1,6 @@
 """The reference's examples solved end to end on the device (od_ilqr_solve), wall time per solve on one MI355X, 1 / 64 / 1024 problems
 (perturbed initial controls): acrobot swing-up, cartpole (frictionless), planar push rotate / translate, the hopper's gait problem (initial configuration fixed), rocket landing with the
-thrust-cone projection and its constraints (fp64 and fp32).  `python tools/time_examples_device.py > profiles/r4_examples_device.json`"""
+thrust-cone projection and its constraints (fp64 and fp32).  `python tools/time_examples_device.py > profiles/r5_examples_device.json`"""
 import os, sys, time, json, math
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -43,6 +43,8 @@ for B in (1, 64, 1024):
     for mode in ("rotate", "translate"):
         run("planar push %s (examples/planar_push.jl)" % mode, lambda b, mode=mode: (lambda r: (r[0], r[1], r[2], r[3], r[5], r[6], tuple(2.0 ** -i for i in range(17))))(C.planar_push_example(lib, dev, mode, b)), B)
     run("hopper gait, initial configuration fixed (examples/hopper.jl)", lambda b: (lambda r: (r[0], r[1], r[2], r[3], r[5], r[6], tuple(2.0 ** -i for i in range(17))))(C.hopper_example(lib, dev, b)), B)
+    run("hopper gait AS SHIPPED: initial configurations optimised, nonlinear foot constraint (examples/hopper.jl, od_ilqr_set_parameter_stage)",
+        lambda b: (lambda r: (r[0], r[1], r[2], r[3], r[5], r[6], tuple(2.0 ** -i for i in range(17))))(C.hopper_example_full(lib, dev, b)), B)
     for dt_ in (torch.float64, torch.float32):
         run("rocket landing, projection + constraints, %s (examples/rocket.jl)" % ("fp64" if dt_ == torch.float64 else "fp32"),
             lambda b, dt_=dt_: (lambda r: (r[0], r[1], r[2], r[3], 60, r[5], r[6]))(C.rocket_example_problem(lib, dev, b, dtype=dt_)), B)
