@@ -8,9 +8,10 @@ state, later stages ignore (and lightly penalise) controls 3..10.  The stage Jac
 maps; the reference's f1u sets d(q2 slot)/d(theta_1) = I and omits d(theta)/d(theta) (examples/hopper.jl:93-99), which
 reads like an indexing slip and is not reproduced.
 `python examples/hopper_gait.py [P]` solves P copies.
-`python examples/hopper_gait.py device [P]` solves the same gait with the initial configurations held at the standing pose (what the
-device-resident solver's uniform stages can express: stage-t objective, control limits, the terminal constraint with theta = x1) by
-od_ilqr_solve -- the whole solve on the GPU, no host round trip per iteration."""
+`python examples/hopper_gait.py device [P]` solves the example AS SHIPPED -- initial configurations optimised through the parameter stage
+(od_ilqr_set_parameter_stage), the generated foot-position constraint, the terminal constraint coupled with theta -- by od_ilqr_solve: the
+whole solve on the GPU, no host round trip per iteration.  `python examples/hopper_gait.py device-fixed [P]`: the same gait with the
+initial configurations held at the standing pose (uniform stages only)."""
 import sys
 
 import numpy as np
@@ -130,6 +131,32 @@ def problem(P=1, T=21, h=0.05, device="cuda", lib=None, **opts):
     return solver, X1, U0
 
 
+def problem_device_full(P=1, T=21, h=0.05, device="cuda", lib=None):
+    """examples/hopper.jl as shipped for od_ilqr_solve (parameter stage): (ILQR solver, theta0, U0, options)"""
+    from optimization_dynamics_amd import ilqr as IL
+    od.hopper.friction[:] = [0.5, 0.5]
+    im = od.ImplicitDynamics(od.hopper, h, r_tol=1.0e-8, kappa_eval_tol=1.0e-4, kappa_grad_tol=1.0e-3, device=device, lib=lib)
+    foot_radius, gravity, mass_body = 0.05, 9.81, 3.0
+    q1 = np.array([0.0, 0.5 + foot_radius, 0.0, 0.5]); q_ref = np.array([0.5, 0.75 + foot_radius, 0.0, 0.25])
+    x1v, x_ref = np.concatenate([q1, q1]), np.concatenate([q_ref, q_ref])
+    w = np.array([1.0, 10.0, 1.0, 10.0] * 2)
+    obj = IL.QuadraticObjective(0.1 * np.diag(w), 0.1 * np.eye(NU), np.eye(2 * NQ), x_ref=x_ref, device=im.device)              # objt / objT, hopper.jl:212-226
+    obj.set_constraints(stage=(np.zeros((4, 2 * NQ)), np.vstack([-np.eye(NU), np.eye(NU)]), np.full(4, 10.0), 4))               # control limits, :236-238,251-254
+    Ctx = np.zeros((8, 2 * NQ)); Cth = np.zeros((8, 2 * NQ)); dt = np.zeros(8)                                                  # terminal_con, :256-262
+    Ctx[0, 0], Cth[0, 0], dt[0] = -1.0, 1.0, -0.5
+    Ctx[1, NQ], Cth[1, NQ], dt[1] = -1.0, 1.0, -0.5
+    for k, i in enumerate([1, 2, 3, NQ + 1, NQ + 2, NQ + 3]):
+        Ctx[2 + k, i], Cth[2 + k, i] = 1.0, -1.0
+    obj.set_parameter_stage(np.array([1.0e-1] * NQ + [1.0e-5] * NQ), constraint="hopper_foot", p=x1v, terminal=(Ctx, Cth, dt, 2),      # obj1's weights on theta (:209), stage1_con (:240-247)
+                            cost_const=0.5 * float((x1v - x_ref) @ (w * (x1v - x_ref))))
+    U0 = np.zeros((NU, T - 1, P)); U0[1] = gravity * mass_body * 0.5 * h                                                        # hopper.jl:270
+    U0[:, :, 1:] += 1e-2 * np.random.default_rng(1).normal(size=(NU, T - 1, P - 1))
+    solver = IL.ILQR(im, obj, T - 1, alphas=tuple(2.0 ** -i for i in range(17)))
+    opts = dict(max_iter=10, max_al_iter=15, con_tol=1.0e-3, obj_tol=1.0e-3, rho_init=1.0, rho_scale=10.0)                      # hopper.jl:273-282
+    dev = im.device
+    return solver, torch.tensor(np.repeat(x1v[:, None], P, axis=1), device=dev), torch.tensor(U0, device=dev), opts
+
+
 def problem_device(P=1, T=21, h=0.05, device="cuda", lib=None):
     """the gait with theta = x1 for od_ilqr_solve: (ILQR solver, x1, U0, options)"""
     from optimization_dynamics_amd import ilqr as IL
@@ -155,16 +182,18 @@ def problem_device(P=1, T=21, h=0.05, device="cuda", lib=None):
 
 if __name__ == "__main__":
     import time
-    if len(sys.argv) > 1 and sys.argv[1] == "device":
+    if len(sys.argv) > 1 and sys.argv[1] in ("device", "device-fixed"):
         P = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-        solver, x1, U0, opts = problem_device(P)
+        solver, x1, U0, opts = (problem_device_full if sys.argv[1] == "device" else problem_device)(P)
         solver.solve(x1, U0, **dict(opts, max_iter=1, max_al_iter=1)); solver._dev = None      # buffers, lazy loads
         torch.cuda.synchronize(); t0 = time.time()
         X, U, J, hist = solver.solve(x1, U0, **opts)
         torch.cuda.synchronize(); dt = time.time() - t0
         info = solver._dev.info(); fl, viol, rho = solver._dev.status()
         print("device-resident solve, %d problem(s): %d iterations, %d multiplier rounds, %.3f s" % (P, info.iterations, info.al_iterations, dt))
-        print("max constraint violation %.2e, travel %.3f m, objective %.3f .. %.3f" % (viol.max().item(), X[NQ, -1].min().item(), J.min().item(), J.max().item()))
+        print("max constraint violation %.2e, travel %.3f m, objective %.3f .. %.3f" % (viol.max().item(), (X[NQ, -1] - X[NQ, 0]).min().item(), J.min().item(), J.max().item()))
+        if sys.argv[1] == "device":
+            print("optimised initial configurations theta = [q1; q2] of problem 0:", np.array2string(X[:, 0, 0].cpu().numpy(), precision=4))
         print("configurations q_t of problem 0 (x, z, angle, leg):")
         print(np.array2string(X[NQ:2 * NQ, :, 0].T.cpu().numpy()[::4], precision=3))
         sys.exit(0)

@@ -75,3 +75,13 @@ def test_cartpole_frictionless_swing_up_gpu(gpu_lib):
     U0[:, 0, 1] = -1.4
     X, U = solver.solve(x1, U0)
     assert (X[:, -1] - xT[:, None]).abs().max().item() <= 5.0e-3            # con_tol of examples/cartpole.jl:92
+
+
+def test_hopper_gait_device_script_cpu(emu_lib):
+    """examples/hopper_gait.py `device` mode: the example as shipped through od_ilqr_solve (host build here)"""
+    import hopper_gait
+    solver, x1, U0, opts = hopper_gait.problem_device_full(1, device="cpu", lib=emu_lib)
+    X, U, J, hist = solver.solve(x1, U0, **opts)
+    fl, viol, rho = solver._dev.status()
+    assert viol.max().item() < 1e-3 and (X[4, -1] - X[4, 0]).min().item() >= 0.5 - 1e-3
+    assert solver._dev.info().iterations == 33
