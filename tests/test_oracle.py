@@ -219,3 +219,24 @@ def test_projection_arbiter_in_binary128(oracle):
         off += d >= 1e-7
         assert d < 5e-4
     assert off <= 12                         # measured: 7-8 % of the controls (profiles/r3_projection_paths.json)
+
+
+def test_ilqr_oracle_against_its_golden_record(oracle):
+    """tests/golden/ilqr_v1.json (tests/golden/make_golden_ilqr.py): the numpy AL-iLQR's decision sequences on examples/hopper.jl as
+    shipped and on the cartpole task with two multiplier rounds -- this oracle's own output, a regression pin across machines and
+    library versions (the accepted step indices are integers: any change of the rules or of the oracle's dynamics shows)"""
+    import json
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden_ilqr as G
+    want = json.load(open(os.path.join(here, "golden", "ilqr_v1.json")))
+    got = G.cases()
+    for case in want:
+        w, g = want[case], got[case]
+        assert g["steps"] == w["steps"] and g["rounds"] == w["rounds"], case
+        assert abs(g["violation"] - w["violation"]) <= 1e-9 + 1e-6 * abs(w["violation"])
+        assert np.allclose(g["x_T"], w["x_T"], rtol=0, atol=1e-8)
+    assert np.allclose(got["hopper_gait_as_shipped"]["theta"], want["hopper_gait_as_shipped"]["theta"], rtol=0, atol=1e-8)
+    assert np.allclose(got["cartpole_two_rounds"]["costs"], want["cartpole_two_rounds"]["costs"], rtol=1e-9, atol=0)
