@@ -132,3 +132,55 @@ def test_handle_reports_its_device_gpu(gpu_lib):
         D, st, it = im.step(torch.tensor(X), torch.tensor(U))
     s.synchronize()
     assert ((st & 1) == 1).double().mean().item() > 0.95
+
+
+def test_parameter_stage_argument_checks(emu_lib):
+    """od_ilqr_set_parameter_stage / od_constraint_* / od_ilqr_get_trace / od_soc_project_full: wrong arguments are error codes"""
+    from optimization_dynamics_amd import _lib, models, rocket as rk
+    cd = emu_lib.cdll
+    assert cd.od_num_constraints() >= 1 and cd.od_constraint_id(b"hopper_foot") == 0 and cd.od_constraint_id(b"no_such_rows") == -1
+    assert cd.od_constraint_name(0) == b"hopper_foot" and cd.od_constraint_name(99) is None
+    nc, nx, npar = C.c_int(), C.c_int(), C.c_int()
+    assert cd.od_constraint_dims(0, C.byref(nc), C.byref(nx), C.byref(npar)) == 0 and (nc.value, nx.value, npar.value) == (8, 8, 8)
+    assert cd.od_constraint_dims(99, None, None, None) == -1
+    al = (C.c_double * 2)(1.0, 0.5)
+    dp = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))
+    w8, p8 = np.full(8, 0.1), np.zeros(8)
+    # a hopper solver: the constraint fits (8 variables); wrong parameter count, unknown id, too many rows are refused
+    im = P.make_im("hopper", emu_lib, "cpu")
+    s = C.c_void_p()
+    emu_lib.check(cd.od_ilqr_create(im._h, 2, 4, 2, al, None, C.byref(s)))
+    q = _lib.IlqrParameterStage()
+    q.constraint, q.n_p, q.p, q.w_theta = 0, 8, dp(p8), dp(w8)
+    assert cd.od_ilqr_set_parameter_stage(s, C.byref(q)) == 0
+    q.n_p = 3
+    assert cd.od_ilqr_set_parameter_stage(s, C.byref(q)) == -1 and b"8 parameters" in cd.od_last_error()
+    q.n_p, q.constraint = 8, 7
+    assert cd.od_ilqr_set_parameter_stage(s, C.byref(q)) == -1
+    q.constraint, q.nt = 0, 17
+    assert cd.od_ilqr_set_parameter_stage(s, C.byref(q)) == -1
+    q.nt, q.w_theta = 0, None
+    assert cd.od_ilqr_set_parameter_stage(s, C.byref(q)) == -1
+    assert cd.od_ilqr_set_parameter_stage(s, None) == 0                      # removes the stage
+XX
+    assert cd.od_ilqr_destroy(s) == 0
+    # a cartpole solver: theta has 4 entries, the hopper's rows act on 8
+    imc = P.make_im("cartpole_friction", emu_lib, "cpu")
+    emu_lib.check(cd.od_ilqr_create(imc._h, 2, 4, 2, al, None, C.byref(s)))
+    q = _lib.IlqrParameterStage()
+    q.constraint, q.n_p, q.p, q.w_theta = 0, 8, dp(p8), dp(w8)
+    assert cd.od_ilqr_set_parameter_stage(s, C.byref(q)) == -1 and b"theta has 4" in cd.od_last_error()
+    q.constraint, q.n_p, q.p = -1, 0, None
+    assert cd.od_ilqr_set_parameter_stage(s, C.byref(q)) == 0                # no generated rows: cost on theta only
+    assert cd.od_ilqr_destroy(s) == 0
+    # a rocket solver has no configurations to optimise
+    info = rk.RocketInfo(models.rocket, 12.5, 0.05, device="cpu", lib=emu_lib)
+    emu_lib.check(cd.od_ilqr_create(info._h, 2, 4, 2, al, None, C.byref(s)))
+    assert cd.od_ilqr_set_parameter_stage(s, C.byref(q)) == -2               # OD_ERR_UNSUPPORTED
+    assert cd.od_ilqr_destroy(s) == 0
+    # od_soc_project_full: empty batch is a no-op, null outputs are refused, a mechanical handle is unsupported
+    u = torch.zeros(3, 4, dtype=torch.float64); z = torch.zeros(10, 4, dtype=torch.float64)
+    assert cd.od_soc_project_full(info._h, 0, u.data_ptr(), z.data_ptr(), None, None, None) == 0
+    assert cd.od_soc_project_full(info._h, 4, u.data_ptr(), None, None, None, None) == -1
+    assert cd.od_soc_project_full(im._h, 4, u.data_ptr(), z.data_ptr(), None, None, None) == -2
+    assert cd.od_soc_project_full(info._h, 4, u.data_ptr(), z.data_ptr(), None, None, None) == 0 and torch.isfinite(z).all()
