@@ -162,7 +162,8 @@ def test_parameter_stage_argument_checks(emu_lib):
     q.nt, q.w_theta = 0, None
     assert cd.od_ilqr_set_parameter_stage(s, C.byref(q)) == -1
     assert cd.od_ilqr_set_parameter_stage(s, None) == 0                      # removes the stage
-XX
+    assert cd.od_ilqr_get_trace(s, None, None, None, 0) == 0                 # (no iterations yet: no rows)
+    assert cd.od_ilqr_get_trace(None, None, None, None, 0) < 0
     assert cd.od_ilqr_destroy(s) == 0
     # a cartpole solver: theta has 4 entries, the hopper's rows act on 8
     imc = P.make_im("cartpole_friction", emu_lib, "cpu")
