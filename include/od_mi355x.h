@@ -294,7 +294,9 @@ int od_ilqr_al_update(od_ilqr s);
  * enqueued in chunks; the host waits only for the chunk before the previous one (the queue never drains) to stop early. */
 int od_ilqr_solve(od_ilqr s, const double* x1, const double* U0);
 /* results (device pointers, doubles, any may be NULL): X n per slot ((T+1)*B), U m per knot, J per trajectory (with the
- * multiplier terms), K (m x n col-major per knot) and k of the last backward pass.  Asynchronous. */
+ * multiplier terms), K (m x n col-major per knot) and k of the last backward pass.  With a parameter stage slot 0 of X is the
+ * optimised theta, K is the feedback on the mechanical state (zero at knot 0, where the state is the stage's control) and k the
+ * feed-forward of the m mechanical controls.  Asynchronous. */
 int od_ilqr_get(od_ilqr s, double* X, double* U, double* J, double* K, double* k);
 /* hist: up to `cap` rows of B costs (row i = costs after iteration i), device pointer; returns the number of rows kept so far
  * (synchronises) or a negative error */

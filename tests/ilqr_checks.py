@@ -833,6 +833,10 @@ def check_hopper_example_full(oracle, lib, device, B=1, n_oracle=1):
     # the returned trajectory is the rollout of its controls from its theta
     Xr = im.rollout(X[:, 0].contiguous(), U, grads=False)[0]
     assert (Xr - X).abs().max().item() < 1e-9
+    # od_ilqr_get's gains with a parameter stage: feedback on the mechanical state (none at knot 0), feed-forward of the mechanical controls
+    Kg, kg = [a.cpu().numpy() for a in d.get(gains=True)[3:]]
+    assert Kg.shape == (2 * 8, T, B) and kg.shape == (2, T, B) and np.isfinite(Kg).all() and np.isfinite(kg).all()
+    assert (Kg[:, 0] == 0).all() and (np.abs(Kg[:, 1:]).max(axis=0) > 0).all()
     stats = dict(problems=B, iterations=int(info.iterations), rounds=int(info.al_iterations), violation_max=float(viol.max()),
                  objective=[float(v) for v in J[: min(B, 4)].cpu().numpy()], agreeing_iterations=[], iterations_oracle=[])
     sim = oracle.make_sim("hopper", 0.05, kappa_tol=1e-4, kappa_grad_tol=1e-3, friction=[0.5, 0.5])

@@ -111,3 +111,38 @@ def test_ilqr_iteration_in_a_graph(gpu_lib, problem, dtype):
         torch.cuda.synchronize()
     for a, b in zip(got, want):
         assert torch.equal(a, b)
+
+
+def test_ilqr_iteration_with_parameter_stage_in_a_graph(gpu_lib):
+    """the parameter stage (examples/hopper.jl:52-99,234-266 through od_ilqr_set_parameter_stage: embedded first stage, generated
+    constraint function, coupled terminal rows) adds kernels only: one recorded iteration replayed n times == n direct iterations,
+    bit for bit, the optimised parameters (slot 0 of the trajectory) included"""
+    import ilqr_checks as C
+    import optimization_dynamics_amd as od
+    B, n_it = 24, 7
+    im, obj, x1, U0, x1v, T, opts = C.hopper_example_full(gpu_lib, "cuda:0", B)
+    x1t, Ut = torch.tensor(x1, device="cuda:0"), torch.tensor(U0, device="cuda:0")
+    sol = od.ILQR(im, obj, T)
+    direct = sol.device_solver(B, max_iter=n_it, obj_tol=0.0)
+    direct.init(x1t, Ut)
+    direct.iterate(n_it)
+    want = direct.get(gains=True) + (direct.history(),)
+    assert want[-1].shape[0] == n_it
+    assert (want[0][:, 0] - x1t).abs().max().item() > 1e-4, "the parameters did not move: the stage is not active"
+    rec = sol.device_solver(B, max_iter=n_it, obj_tol=0.0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        rec.init(x1t, Ut)
+        rec.iterate(1)
+        rec.init(x1t, Ut)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            rec.iterate(1)
+        for _ in range(n_it):
+            g.replay()
+        torch.cuda.synchronize()
+        got = rec.get(gains=True) + (rec.history(),)
+        torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
