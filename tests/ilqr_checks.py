@@ -487,6 +487,62 @@ def check_rocket_example(lib, device, B=1, dtype=torch.float64):
     return info
 
 
+def rocket_example_nominal_problem(lib, device, B, dtype=torch.float64):
+    """examples/rocket.jl with `MODE = :nominal` -- what the file runs as shipped (:11-12, the second assignment wins): f_rocket without
+    the projection (:30-35), the thrust limits as stage constraints -1 <= u[1:2] <= 1, 0 <= u[3] <= u_max together with
+    length - x[3] <= 0 (:89-99, seven inequalities), the terminal constraints and solver options of the `:projection` mode"""
+    from optimization_dynamics_amd import rocket as rk
+    dyn, obj, x1, U0 = config5_problem(lib, device, B, dtype=dtype)
+    dyn = rk.RocketDynamics(dyn.info, project=False)
+    xT = obj.x_ref.cpu().numpy()
+    n, m = 12, 3
+    Cs = np.zeros((7, n)); Ds = np.zeros((7, m)); ds = np.zeros(7)
+    for j in range(2):
+        Ds[2 * j, j], ds[2 * j] = -1.0, 1.0
+        Ds[2 * j + 1, j], ds[2 * j + 1] = 1.0, 1.0
+    Ds[4, 2], ds[4] = -1.0, 0.0
+    Ds[5, 2], ds[5] = 1.0, 12.5
+    Cs[6, 2], ds[6] = -1.0, -1.0
+    Ct = np.zeros((14, n)); dt = np.zeros(14)
+    Ct[0, 0] = -1.0; dt[0] = 0.5; Ct[1, 0] = 1.0; dt[1] = 0.5
+    Ct[2, 1] = -1.0; dt[2] = 0.75; Ct[3, 1] = 1.0; dt[3] = 0.75
+    for k in range(10):
+        Ct[4 + k, 2 + k] = 1.0; dt[4 + k] = xT[2 + k]
+    obj.set_constraints(stage=(Cs, Ds, ds, 7), terminal=(Ct, dt, 4))
+    opts = dict(max_iter=100, max_al_iter=15, con_tol=0.005, obj_tol=1.0e-3, rho_init=1.0, rho_scale=10.0)
+    alphas = tuple(2.0 ** -i for i in range(17))
+    return dyn, obj, x1, U0, xT, opts, alphas
+
+
+def check_rocket_example_nominal(lib, device, B=4, dtype=torch.float64, need=0.5):
+    """the rocket example as shipped (`:nominal`) through od_ilqr_solve.  The landing has two basins from initial controls of 1e-3 randn
+    (examples/rocket.jl:116-117; Julia's stream of seed 1 cannot be drawn here): most starts end at the landing with every constraint
+    at con_tol, the others flip the rocket over in the FIRST multiplier round (rho = 1) and stay infeasible -- a property of the
+    problem's landscape, each problem being an independent solve.  At least `need` of the starts must land, and for those: thrust
+    limits, floor, terminal box and terminal state to con_tol, flags == 3"""
+    dyn, obj, x1, U0, xT, opts, alphas = rocket_example_nominal_problem(lib, device, B, dtype=dtype)
+    sol = IL.ILQR(dyn, obj, 60, alphas=alphas)
+    X, U, J, hist = sol.solve(torch.tensor(x1, device=device), torch.tensor(U0, device=device), **opts)
+    info = sol._dev.info()
+    fl, viol, rho = sol._dev.status()
+    ok = (fl == 3)
+    assert ok.double().mean().item() >= need, fl.cpu().numpy()
+    assert torch.equal(ok, viol < opts["con_tol"])
+    assert (obj.violation(X, U) - viol).abs().max().item() < 1e-9 * max(1.0, viol.max().item())
+    Xo, Uo = X[:, :, ok], U[:, :, ok]
+    tol = opts["con_tol"]
+    assert (Uo[:2].abs() <= 1.0 + tol).all() and (Uo[2] >= -tol).all() and (Uo[2] <= 12.5 + tol).all()
+    assert (Xo[2, :-1] >= 1.0 - tol).all()
+    assert (Xo[0, -1].abs() <= 0.5 + tol).all() and (Xo[1, -1].abs() <= 0.75 + tol).all()
+    assert (Xo[2:, -1] - torch.tensor(xT[2:], device=device)[:, None]).abs().max().item() < tol
+    cone = (torch.hypot(Uo[0], Uo[1]) <= Uo[2] + tol).double().mean().item()        # (:151: not a constraint of this mode)
+    print("rocket example as shipped (:nominal), %d problem(s), %s: %d of them land, %d iterations, %d multiplier updates, objective %.1f .. %.1f, "
+          "thrust inside the cone at %.0f %% of the knots" % (B, str(dtype).split(".")[-1], int(ok.sum()), info.iterations, info.al_iterations,
+                                                           obj.value(Xo, Uo).min().item(), obj.value(Xo, Uo).max().item(), 100 * cone))
+    return dict(problems=B, landed=int(ok.sum()), iterations=int(info.iterations), rounds=int(info.al_iterations),
+                objective=[obj.value(Xo, Uo).min().item(), obj.value(Xo, Uo).max().item()], cone_fraction=cone)
+
+
 def planar_push_example(lib, device, mode, B, seed=1):
     """examples/planar_push.jl (`:rotate` / `:translate`): h = 0.1, T = 26, kappa_eval 1e-4, kappa_grad 1e-2 (:18-22); objective
     1/2 v1'W v1 + 1/2 (x - xT)'Wx (x - xT) + 1/2 ru u'u per stage, without the control term at the horizon (:57-83) -- a quadratic

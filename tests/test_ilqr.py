@@ -169,6 +169,20 @@ def test_rocket_example_with_its_constraints_gpu(gpu_lib):
     C.check_rocket_example(gpu_lib, "cuda:0", B=64, dtype=torch.float32)
 
 
+def test_rocket_example_as_shipped_nominal_cpu(emu_lib):
+    """examples/rocket.jl with the mode the file ends up in (`:nominal`, :11-12): thrust limits as stage constraints, no projection"""
+    C.check_rocket_example_nominal(emu_lib, "cpu", B=4)
+
+
+@pytest.mark.gpu
+def test_rocket_example_as_shipped_nominal_gpu(gpu_lib):
+    import json, os
+    r = C.check_rocket_example_nominal(gpu_lib, "cuda:0", B=64)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/rocket_example_nominal.json", "w") as f:
+        json.dump(r, f, indent=1)
+
+
 def test_reference_examples_on_the_device_cpu(emu_lib):
     """examples/cartpole.jl (frictionless, the file's default) and examples/planar_push.jl `:translate` through od_ilqr_solve, one problem each (host build)"""
     C.check_reference_example(emu_lib, "cpu", "cartpole:frictionless")
@@ -179,6 +193,18 @@ def test_reference_examples_on_the_device_cpu(emu_lib):
 @pytest.mark.parametrize("which", ["cartpole:frictionless", "planar_push:rotate", "planar_push:translate"])
 def test_reference_examples_on_the_device_gpu(gpu_lib, which):
     C.check_reference_example(gpu_lib, "cuda:0", which, B=32, need=0.9)
+
+
+def test_cartpole_friction_example_on_the_device_cpu(emu_lib):
+    """examples/cartpole.jl `:friction` (:11, joint friction 0.35, kappa_eval 1e-4 / kappa_grad 1e-3): the swing-up through the friction
+    cones is sensitive to its start (the example's own comment at :77 retunes the first control per friction coefficient); of starts
+    perturbed by 1e-2 more than half reach the goal to con_tol, each an independent solve"""
+    C.check_reference_example(emu_lib, "cpu", "cartpole:friction", B=8, need=0.5)
+
+
+@pytest.mark.gpu
+def test_cartpole_friction_example_on_the_device_gpu(gpu_lib):
+    C.check_reference_example(gpu_lib, "cuda:0", "cartpole:friction", B=64, need=0.5)
 
 
 def test_hopper_example_on_the_device_cpu(emu_lib):

@@ -42,6 +42,9 @@ for B in (1, 64, 1024):
     run("cartpole frictionless (examples/cartpole.jl)", lambda b: (lambda r: (r[0], r[1], r[2], r[3], r[5], r[6], tuple(2.0 ** -i for i in range(17))))(C.cartpole_example(lib, dev, "frictionless", b)), B)
     for mode in ("rotate", "translate"):
         run("planar push %s (examples/planar_push.jl)" % mode, lambda b, mode=mode: (lambda r: (r[0], r[1], r[2], r[3], r[5], r[6], tuple(2.0 ** -i for i in range(17))))(C.planar_push_example(lib, dev, mode, b)), B)
+    run("cartpole with joint friction 0.35 (examples/cartpole.jl `:friction`)", lambda b: (lambda r: (r[0], r[1], r[2], r[3], r[5], r[6], tuple(2.0 ** -i for i in range(17))))(C.cartpole_example(lib, dev, "friction", b)), B)
+    run("rocket landing AS SHIPPED (`:nominal`: thrust limits as stage constraints, no projection; examples/rocket.jl)",
+        lambda b: (lambda r: (r[0], r[1], r[2], r[3], 60, r[5], r[6]))(C.rocket_example_nominal_problem(lib, dev, b)), B)
     run("hopper gait, initial configuration fixed (examples/hopper.jl)", lambda b: (lambda r: (r[0], r[1], r[2], r[3], r[5], r[6], tuple(2.0 ** -i for i in range(17))))(C.hopper_example(lib, dev, b)), B)
     run("hopper gait AS SHIPPED: initial configurations optimised, nonlinear foot constraint (examples/hopper.jl, od_ilqr_set_parameter_stage)",
         lambda b: (lambda r: (r[0], r[1], r[2], r[3], r[5], r[6], tuple(2.0 ** -i for i in range(17))))(C.hopper_example_full(lib, dev, b)), B)
