@@ -150,3 +150,46 @@ def test_null_arguments_are_error_codes_not_crashes(emu_lib):
 @pytest.mark.gpu
 def test_null_arguments_are_error_codes_not_crashes_on_the_gpu(gpu_lib):
     _null_fuzz(gpu_lib, "cuda:0")
+
+
+# ---- the boundary from plain C (tests/c_abi/abi_client.c): what a cgo / ccall / JNI binding sees ------------------------------------
+def _build_c_client(tmp_path, built):
+    exe = str(tmp_path / "abi_client")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi", "abi_client.c"), "-o", exe,
+                           "-L", os.path.dirname(built), "-lod_mi355x", "-Wl,-rpath," + os.path.dirname(built)])
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_caller_links(tmp_path, built):
+    """include/od_mi355x.h compiles as pedantic C99 without warnings, a C program links against the library with nothing else, reads the
+    model table -- and without a GPU od_create refuses with OD_ERR_NO_DEVICE and its message (no CPU path behind the boundary)"""
+    import torch
+    exe = _build_c_client(tmp_path, built)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert "hopper nq 4 nu 2 nz 20 ntheta 13" in r.stdout and "hopper_foot 0" in r.stdout, r.stdout + r.stderr
+    if not torch.cuda.is_available():
+        assert r.returncode == 77 and "no device" in r.stdout and "no CPU path" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.gpu
+def test_c_caller_computes_what_the_python_mirror_and_the_oracle_compute(tmp_path, built, gpu_lib, oracle):
+    """the C program's f / fx / fu of one hopper step (od_ffxfu_host, od_f_host) == the Python mirror's callbacks bit for bit (same
+    library, same entry points), and the oracle's step at 1e-6 / 1e-4 (BASELINE north_star's tolerances)"""
+    import numpy as np
+    import parity_checks as P
+    from optimization_dynamics_amd import dynamics as dyn
+    exe = _build_c_client(tmp_path, built)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    rows = {l.split()[0]: np.array([float(v) for v in l.split()[1:]]) for l in r.stdout.splitlines() if l.split()[0] in ("d", "dx", "du")}
+    d, dx, du = rows["d"], rows["dx"].reshape(8, 8, order="F"), rows["du"].reshape(8, 2, order="F")
+    x = np.array([0.0, 0.55, 0.0, 0.5, 0.0, 0.55, 0.0, 0.5]); u = np.array([0.0, 0.73575])
+    im = P.make_im("hopper", gpu_lib, "cuda:0")
+    d2 = np.zeros(8); dx2 = np.zeros((8, 8)); du2 = np.zeros((8, 2))
+    dyn.ffxfu(d2, dx2, du2, im, x, u)
+    assert np.array_equal(d, d2) and np.array_equal(dx, dx2) and np.array_equal(du, du2)
+    Xo, Ao, Bo, bad = oracle.rollout(P.make_sim(oracle, "hopper"), x[:, None], u[:, None, None])
+    assert bad == 0
+    assert np.abs(d - Xo[:, 1, 0]).max() < 1e-6
+    assert np.abs(dx - Ao[:, :, 0, 0]).max() < 1e-4 * max(1.0, np.abs(Ao).max()) and np.abs(du - Bo[:, :, 0, 0]).max() < 1e-4 * max(1.0, np.abs(Bo).max())
