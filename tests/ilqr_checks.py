@@ -830,7 +830,10 @@ def check_against_numpy_oracle(oracle, lib, device, case, B=8, seed=1):
 
 
 # ---- examples/hopper.jl AS SHIPPED (the initial configurations optimised through a first stage of its own dimensions) on the device ------
-def hopper_example_full(lib, device, B, seed=1):
+GAITS = {1: (1.0e-1, 1.0e-1), 2: (1.0, 1.0), 3: (1.0e-3, 1.0e-1)}      # (r_cost, q_cost), examples/hopper.jl:190-203
+
+
+def hopper_example_full(lib, device, B, seed=1, gait=1):
     """examples/hopper.jl:12-13,42-50,176-290, GAIT 1: T = 21, h = 0.05; u_1 = [u; theta] with theta = [q1; q2] the two initial
     configurations (od_ilqr_set_parameter_stage: slot 0 of the trajectory), obj1 / objt / objT (:207-226), stage1_con (control limits,
     q1 fixed, foot positions: the generated `hopper_foot`), staget_con (control limits), terminal_con (:256-262, couples x_T with theta).
@@ -842,7 +845,8 @@ def hopper_example_full(lib, device, B, seed=1):
     q1 = np.array([0.0, 0.5 + r, 0.0, 0.5]); q_ref = np.array([0.5, 0.75 + r, 0.0, 0.25])
     x1v, x_ref = np.concatenate([q1, q1]), np.concatenate([q_ref, q_ref])
     w = np.array([1.0, 10.0, 1.0, 10.0] * 2)
-    obj = IL.QuadraticObjective(0.1 * np.diag(w), 0.1 * np.eye(2), np.eye(8), x_ref=x_ref, device=device)
+    r_cost, q_cost = GAITS[gait]
+    obj = IL.QuadraticObjective(q_cost * np.diag(w), r_cost * np.eye(2), np.eye(8), x_ref=x_ref, device=device)
     Cs = np.zeros((4, 8)); Ds = np.vstack([-np.eye(2), np.eye(2)]); ds = np.full(4, 10.0)
     obj.set_constraints(stage=(Cs, Ds, ds, 4))
     Ctx = np.zeros((8, 8)); Cth = np.zeros((8, 8)); dt = np.zeros(8)
@@ -860,14 +864,14 @@ def hopper_example_full(lib, device, B, seed=1):
     return im, obj, x1, U0, x1v, T, opts
 
 
-def check_hopper_example_full(oracle, lib, device, B=1, n_oracle=1):
+def check_hopper_example_full(oracle, lib, device, B=1, n_oracle=1, gait=1):
     """examples/hopper.jl as shipped through od_ilqr_solve -- parameter stage, generated nonlinear constraint, coupled terminal rows --
     against oracle/ilqr_np.py::solve_stages on the reference's own formulation (stages of dimensions 8 / 10 -> 16 and 16 / 2 -> 16,
     constraint functions as the example writes them) with the oracle's dynamics: the decisions of every iteration on the first
     `n_oracle` problems (accepted step index, regularisation, penalty, merit), the optimised initial configurations, the
     constraints to con_tol on every problem"""
     from oracle import ilqr_np as N
-    im, obj, x1, U0, x1v, T, opts = hopper_example_full(lib, device, B)
+    im, obj, x1, U0, x1v, T, opts = hopper_example_full(lib, device, B, gait=gait)
     alphas = tuple(2.0 ** -i for i in range(17))
     sol = IL.ILQR(im, obj, T, alphas=alphas)
     X, U, J, hist = sol.solve(torch.tensor(x1, device=device), torch.tensor(U0, device=device), **opts)
@@ -893,11 +897,11 @@ def check_hopper_example_full(oracle, lib, device, B=1, n_oracle=1):
     Kg, kg = [a.cpu().numpy() for a in d.get(gains=True)[3:]]
     assert Kg.shape == (2 * 8, T, B) and kg.shape == (2, T, B) and np.isfinite(Kg).all() and np.isfinite(kg).all()
     assert (Kg[:, 0] == 0).all() and (np.abs(Kg[:, 1:]).max(axis=0) > 0).all()
-    stats = dict(problems=B, iterations=int(info.iterations), rounds=int(info.al_iterations), violation_max=float(viol.max()),
+    stats = dict(gait=gait, problems=B, iterations=int(info.iterations), rounds=int(info.al_iterations), violation_max=float(viol.max()),
                  objective=[float(v) for v in J[: min(B, 4)].cpu().numpy()], agreeing_iterations=[], iterations_oracle=[])
     sim = oracle.make_sim("hopper", 0.05, kappa_tol=1e-4, kappa_grad_tol=1e-3, friction=[0.5, 0.5])
     for b in range(min(B, n_oracle)):
-        st, objT, conT, nti, x1o, U0o = N.hopper_gait_stages(sim)
+        st, objT, conT, nti, x1o, U0o = N.hopper_gait_stages(sim, r_cost=GAITS[gait][0], q_cost=GAITS[gait][1])
         U0o = [np.concatenate([U0[:, 0, b], x1v])] + [U0[:, t, b] for t in range(1, T)]
         r = N.solve_stages(st, objT, conT, nti, x1o, U0o, alphas=alphas, reg0=sol.reg, c1=sol.c1, **{k: v for k, v in opts.items()})
         L = r["log"]

@@ -262,6 +262,24 @@ def test_hopper_example_full_on_the_device_gpu(oracle, gpu_lib):
     assert 25 <= st["iterations"] <= 60
 
 
+@pytest.mark.parametrize("gait", [2, 3])
+def test_hopper_example_other_gaits_on_the_device_cpu(oracle, emu_lib, gait):
+    """examples/hopper.jl:190-203: GAIT 2 / GAIT 3 (other cost weights; animations/hopper_gait_2.gif, _3.gif of the reference)"""
+    st = C.check_hopper_example_full(oracle, emu_lib, "cpu", B=1, n_oracle=1, gait=gait)
+    assert st["agreeing_iterations"][0] == st["iterations_oracle"][0] == st["iterations"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gait", [2, 3])
+def test_hopper_example_other_gaits_on_the_device_gpu(oracle, gpu_lib, gait):
+    import json
+    import os
+    st = C.check_hopper_example_full(oracle, gpu_lib, "cuda:0", B=64, n_oracle=2, gait=gait)
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    json.dump(st, open(os.path.join(d, "hopper_example_full_gait%d.json" % gait), "w"), indent=1)
+
+
 def test_constraint_generator_builds_a_new_constraint(tmp_path):
     """python -m optimization_dynamics_amd.codegen --add-constraint: a user's sympy constraint becomes device code (into a scratch root)"""
     import subprocess
