@@ -277,6 +277,13 @@ typedef struct {
   const double *Ct_x, *Ct_theta, *dt;
 } od_ilqr_parameter_stage;
 int od_ilqr_set_parameter_stage(od_ilqr s, const od_ilqr_parameter_stage* ps);
+/* GradientBundle as the solver's linearisation -- examples/planar_push.jl:15,22,29-30 with GB = true: fx_gb / fu_gb
+ * (src/gradient_bundle.jl:109-147) instead of the implicit gradients.  Every linearisation of the nominal trajectory then runs
+ * gradient! on its T*B knots (N + 1 steps of the eval simulator per knot with the samples eta, the least-squares fit of src/ls.jl:
+ * the kernels of od_bundle_grad) and fills fx = [0 I; dz_q1 dz_q2], fu = [0; dz_u].  eta: (2 nq + nu) x N col-major on the HOST
+ * (gb.ls.eta: one non-zero per column, eps * randn at a random coordinate, src/gradient_bundle.jl:49-54); mechanical models, also
+ * with a parameter stage.  N = 0 or eta = NULL: implicit gradients again.  Call before od_ilqr_init. */
+int od_ilqr_set_gradient_bundle(od_ilqr s, int N, const double* eta);
 /* registry of the generated constraint functions (csrc/gen/con_list.h): rows nc on nx variables with np parameters */
 int od_num_constraints(void);
 int od_constraint_id(const char* name);       /* -1 if unknown */

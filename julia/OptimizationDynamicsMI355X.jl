@@ -20,7 +20,8 @@ export ImplicitDynamics, f, fx, fu, state_to_configuration, GradientBundle, fx_g
        RocketInfo, f_rocket, fx_rocket, fu_rocket, f_rocket_proj, fx_rocket_proj, fu_rocket_proj,
        soc_projection, soc_projection_gradient, ffxfu!,
        od_step_grad!, od_rollout!, od_rollout_compact!, od_rocket!, od_soc_project!, od_step_full!, model_indices,
-       ILQRSolver, set_constraints!, get_status!, initialize!, iterate!, al_update!, solve!, get_trajectory!
+       ILQRSolver, set_constraints!, set_parameter_stage!, set_gradient_bundle!, get_status!, get_trace!, initialize!, iterate!, al_update!,
+       solve!, get_trajectory!
 
 const LIB = get(ENV, "OD_MI355X_LIB", joinpath(@__DIR__, "..", "optimization_dynamics_amd", "libod_mi355x.so"))
 
@@ -374,6 +375,20 @@ function set_parameter_stage!(s::ILQRSolver; w_theta, constraint="", p=Float64[]
         ps = Ref(ILQRParameterStage(cid, length(pp), pointer(pp), pointer(w), cost_const, length(d), n_terminal_ineq, pointer(cx), pointer(ct), pointer(d)))
         check(ccall((:od_ilqr_set_parameter_stage, LIB), Cint, (Ptr{Cvoid}, Ref{ILQRParameterStage}), s.s, ps))
     end
+end
+"""
+    set_gradient_bundle!(s, gb)
+
+examples/planar_push.jl with `GB = true` (:15,22,29-30): the solver linearises with fx_gb / fu_gb (src/gradient_bundle.jl:109-147) --
+N + 1 eval-simulator steps per knot with the samples `gb.ls.η` and the least-squares fit -- instead of the implicit gradients.
+`set_gradient_bundle!(s, nothing)` goes back to them.
+"""
+function set_gradient_bundle!(s::ILQRSolver, eta::Union{Nothing,AbstractMatrix})
+    if eta === nothing
+        return check(ccall((:od_ilqr_set_gradient_bundle, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}), s.s, 0, C_NULL))
+    end
+    e = Matrix{Float64}(eta)                       # (2nq + nu) x N, column-major
+    GC.@preserve e check(ccall((:od_ilqr_set_gradient_bundle, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}), s.s, size(e, 2), pointer(e)))
 end
 "per problem: flags (bit 0 inner loop converged, bit 1 constraints met), violation, penalty -- device arrays of length B"
 get_status!(s::ILQRSolver, flags, violation, penalty) =

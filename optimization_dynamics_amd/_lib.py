@@ -97,6 +97,7 @@ SIGNATURES = {
     "od_ilqr_set_constraints": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "od_ilqr_set_parameter_stage": (C.c_int, [_VP, C.POINTER(IlqrParameterStage)]),
+    "od_ilqr_set_gradient_bundle": (C.c_int, [_VP, C.c_int, _VP]),
     "od_num_constraints": (C.c_int, []),
     "od_constraint_id": (C.c_int, [C.c_char_p]),
     "od_constraint_name": (C.c_char_p, [C.c_int]),

@@ -244,9 +244,11 @@ class ILQR:
     """B trajectory optimisations in lockstep."""
 
     def __init__(self, im, objective: QuadraticObjective, T,
-                 alphas=tuple(2.0 ** -i for i in range(11)), reg=1e-6, c1=1e-4):
-        """im: an ImplicitDynamics (mechanical models) or a rocket.RocketDynamics"""
+                 alphas=tuple(2.0 ** -i for i in range(11)), reg=1e-6, c1=1e-4, bundle=None):
+        """im: an ImplicitDynamics (mechanical models) or a rocket.RocketDynamics; bundle: a GradientBundle -- the linearisation is
+        then fx_gb / fu_gb (src/gradient_bundle.jl:109-147, examples/planar_push.jl with GB = true) instead of the implicit gradients"""
         self.im, self.obj, self.T = im, objective, T
+        self.bundle = bundle
         if isinstance(im, ImplicitDynamics):
             self.n, self.m = 2 * im.model.nq, im.model.nu
         else:
@@ -257,6 +259,10 @@ class ILQR:
 
     # -- the three device steps ----------------------------------------------------------------
     def linearize(self, x1, U):
+        if self.bundle is not None:
+            X, st = self.im.rollout(x1, U, grads=False)[0], None
+            A, Bm = self.linearize_at(X, U)
+            return X, A, Bm, st
         X, A, Bm, st, it, _ = self.im.rollout(x1, U)
         return X, A, Bm, st
 
@@ -266,7 +272,18 @@ class ILQR:
         n, m, T = self.n, self.m, self.T
         B = U.shape[-1]
         Xk, Uk = X[:, :-1].reshape(n, T * B), U.reshape(m, T * B)
-        if isinstance(self.im, ImplicitDynamics):
+        if self.bundle is not None:
+            from .gradient_bundle import gradient_batch
+            nq = n // 2
+            dz, st = gradient_batch(self.im, self.bundle, Xk.contiguous(), Uk.contiguous())        # (nq, 2nq+nu, T*B)
+            DX = torch.zeros(n, n, T * B, dtype=torch.float64, device=Xk.device)
+            DU = torch.zeros(n, m, T * B, dtype=torch.float64, device=Xk.device)
+            for i in range(nq):
+                DX[i, nq + i] = 1.0
+            DX[nq:] = dz[:, :n]
+            DU[nq:] = dz[:, n:]
+            self.last_linearisation_ok = (st != 0).view(T, B)
+        elif isinstance(self.im, ImplicitDynamics):
             _, DX, DU, st, _ = self.im.step_grad(Xk, Uk)
             self.last_linearisation_ok = ((st & 3) == 3).view(T, B)
         else:
@@ -542,6 +559,10 @@ class DeviceILQR:
                 q.nt, q.nt_ineq, q.Ct_x, q.Ct_theta, q.dt = dtt.size, ni, dp(keep[-3]), dp(keep[-2]), dp(keep[-1])
             self._keep_ps = keep
             self.lib.check(self.lib.cdll.od_ilqr_set_parameter_stage(self._s, C.byref(q)))
+        if ilqr.bundle is not None:
+            gb = ilqr.bundle
+            self._keep_eta = np.ascontiguousarray(gb.eta.T, dtype=np.float64)           # (nzb x N) column-major == N rows of nzb
+            self.lib.check(self.lib.cdll.od_ilqr_set_gradient_bundle(self._s, int(gb.N), self._keep_eta.ctypes.data_as(C.c_void_p)))
         self.max_hist = history if history > 0 else max_iter * max_al_iter
 
     def __del__(self):

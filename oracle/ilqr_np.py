@@ -303,6 +303,29 @@ def mechanical_dynamics(sim):
     return step, linearise
 
 
+def bundle_dynamics(sim, eta):
+    """f of the oracle with fx_gb / fu_gb (src/gradient_bundle.jl:109-147) as linearisation: gradient! through the oracle's own
+    N + 1 steps and least-squares fit (od_oracle_gradient_bundle) with the samples eta ((2nq + nu) x N)"""
+    from . import oracle as O
+    nq = O.dims(sim.model_id)["nq"]
+
+    def step(x, u):
+        ok, d, it = O.f(sim, x, u)
+        return ok, d
+
+    def linearise(Xk, Uk):
+        T, n, m = Xk.shape[0], Xk.shape[1], Uk.shape[1]
+        A = np.zeros((T, n, n)); Bm = np.zeros((T, n, m))
+        for t in range(T):
+            ok, dz = O.gradient_bundle(sim, eta, Xk[t, :nq], Xk[t, nq:], Uk[t])
+            A[t, :nq, nq:] = np.eye(nq)
+            A[t, nq:, :] = dz[:, :n]
+            Bm[t, nq:, :] = dz[:, n:]
+        return A, Bm
+
+    return step, linearise
+
+
 def rocket_dynamics(h=0.05, u_max=12.5, project=True):
     """f_rocket(_proj), fx / fu_rocket(_proj) of the oracle (src/models/rocket/dynamics.jl:101-268); + a rollout through its batched form"""
     from . import oracle as O

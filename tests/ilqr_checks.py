@@ -829,6 +829,70 @@ def check_against_numpy_oracle(oracle, lib, device, case, B=8, seed=1):
     return stats
 
 
+# ---- examples/planar_push.jl with GB = true: the gradient bundle as the solver's linearisation (od_ilqr_set_gradient_bundle) ------------------
+def check_bundle_linearisation(oracle, lib, device, mode="rotate", B=4, N=50, n_oracle=1, need=1.0):
+    """examples/planar_push.jl:15,22,29-30 with GB = true (GradientBundle(planarpush, N = 50, eps = 1e-4)) through od_ilqr_solve:
+    (1) against the same loop composed on the host from the PUBLIC entry points (od_bundle_grad for every linearisation, decisions in
+        torch): costs iteration by iteration, iteration counts, trajectories;
+    (2) the first `n_oracle` problems against oracle/ilqr_np.py::solve with the ORACLE's bundle (its own N + 1 steps and fit) as
+        linearisation, decision by decision for as long as the two agree -- a zero-order fit divides differences of steps by
+        eps = 1e-4, so what two implementations of a step leave at r_tol = 1e-8 is ~1e-4 in the fitted Jacobians and an Armijo test
+        can fall the other way early; then: same outcome;
+    (3) the example's outcome: goal to con_tol, controls inside their limits."""
+    from oracle import ilqr_np as N_
+    from optimization_dynamics_amd import gradient_bundle as gbm
+    import optimization_dynamics_amd as od
+    im, obj, x1, U0, xT, T, opts = planar_push_example(lib, device, mode, B)
+    gb = gbm.GradientBundle(od.planarpush, N=N, eps=1.0e-4, seed=3)
+    alphas = tuple(2.0 ** -i for i in range(17))
+    x1t, Ut = torch.tensor(x1, device=device), torch.tensor(U0, device=device)
+    sol = IL.ILQR(im, obj, T, alphas=alphas, bundle=gb)
+    X, U, J, hist = sol.solve(x1t, Ut, **opts)
+    d = sol._dev
+    info = d.info()
+    fl, viol, rho = [a.cpu().numpy() for a in d.status()]
+    sel, reg, rh = [a.cpu().numpy() for a in d.trace()]
+    H = torch.stack(hist).cpu().numpy()
+    okc = viol < opts["con_tol"]
+    assert okc.mean() >= need, (okc.mean(), viol.max())
+    assert (U.abs() <= 5.0 + opts["con_tol"]).all()
+    assert (im.rollout(x1t, U, grads=False)[0] - X).abs().max().item() < 1e-9
+    # the implicit gradients give another path: the bundle really is what linearised
+    Xi, Ui, Ji, hi = IL.ILQR(im, obj, T, alphas=alphas).solve(x1t, Ut, **opts)
+    assert (torch.stack(hi)[0] - torch.stack(hist)[0]).abs().max().item() > 1e-9
+    # (1) the host-composed loop with od_bundle_grad
+    ref = IL.ILQR(im, obj, T, alphas=alphas, bundle=gb).solve_stepwise(x1t, Ut, **opts)
+    assert len(ref[3]) == len(hist) == info.iterations, (len(ref[3]), len(hist), info.iterations)
+    for i, (ja, jb) in enumerate(zip(hist, ref[3])):
+        assert ((ja - jb).abs() <= 1e-9 * jb.abs().clamp(min=1.0)).all(), (i, (ja - jb).abs().max().item())
+    assert (X - ref[0]).abs().max().item() < 1e-6 and (U - ref[1]).abs().max().item() < 1e-6
+    stats = dict(mode=mode, problems=B, samples=N, iterations=int(info.iterations), rounds=int(info.al_iterations), fraction_at_con_tol=float(okc.mean()),
+                 violation_max=float(viol.max()), agreeing_iterations=[], iterations_oracle=[], objective=[float(v) for v in J[: min(B, 4)].cpu().numpy()])
+    # (2) the numpy oracle with the oracle's bundle
+    sim = oracle.make_sim("planar_push", 0.1, kappa_tol=1e-4, kappa_grad_tol=1e-2)
+    step, lin = N_.bundle_dynamics(sim, gb.eta)
+    f = lambda t: None if t is None else t.cpu().numpy()
+    for b in range(min(B, n_oracle)):
+        p = N_.Problem(step, lin, f(obj.Q), f(obj.R), f(obj.QT), f(obj.x_ref), goal_idx=f(obj.goal_idx), goal=f(obj.goal), stage=obj.stage, terminal=obj.terminal)
+        r = N_.solve(p, x1[:, b], U0[:, :, b].T, alphas=alphas, reg0=sol.reg, c1=sol.c1, **opts)
+        L = r["log"]
+        rows = [i for i in range(sel.shape[0]) if sel[i, b] != -2]
+        nag = 0
+        for l, i in zip(L, rows):
+            same = l["step"] == sel[i, b] and abs(l["reg"] - reg[i, b]) <= 1e-12 * reg[i, b] and abs(l["rho"] - rh[i, b]) <= 1e-12 * max(1.0, rh[i, b])
+            if not (same and abs(l["J"] - H[i, b]) <= 1e-4 * max(1.0, abs(l["J"]))):
+                break
+            nag += 1
+        stats["agreeing_iterations"].append(nag); stats["iterations_oracle"].append(len(L))
+        assert nag >= min(3, len(L)), (b, nag, len(L))
+        assert r["al_done"] == bool(fl[b] & 2), (b, r["al_done"], fl[b])
+        assert abs(len(L) - len(rows)) <= max(3, len(L) // 2), (len(L), len(rows))
+        assert abs(r["J"] - J[b].item()) <= 0.2 * abs(r["J"]), (r["J"], J[b].item())
+    print("planar push %s with GB = true (N = %d), %d problem(s): %d iterations, %d multiplier rounds, %.0f %% at con_tol, max violation %.2e; "
+          "oracle agrees on %s of %s iterations" % (mode, N, B, info.iterations, info.al_iterations, 100 * okc.mean(), viol.max(), stats["agreeing_iterations"], stats["iterations_oracle"]))
+    return stats
+
+
 # ---- examples/hopper.jl AS SHIPPED (the initial configurations optimised through a first stage of its own dimensions) on the device ------
 GAITS = {1: (1.0e-1, 1.0e-1), 2: (1.0, 1.0), 3: (1.0e-3, 1.0e-1)}      # (r_cost, q_cost), examples/hopper.jl:190-203
 

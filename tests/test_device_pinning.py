@@ -178,6 +178,17 @@ def test_parameter_stage_argument_checks(emu_lib):
     info = rk.RocketInfo(models.rocket, 12.5, 0.05, device="cpu", lib=emu_lib)
     emu_lib.check(cd.od_ilqr_create(info._h, 2, 4, 2, al, None, C.byref(s)))
     assert cd.od_ilqr_set_parameter_stage(s, C.byref(q)) == -2               # OD_ERR_UNSUPPORTED
+    # ... and no simulator step to sample: the gradient bundle is for the mechanical models
+    eta = np.zeros((15, 5))
+    assert cd.od_ilqr_set_gradient_bundle(s, 5, eta.ctypes.data_as(C.c_void_p)) == -2
+    assert cd.od_ilqr_set_gradient_bundle(s, 0, None) == 0                   # (removing what is not there is fine)
+    assert cd.od_ilqr_destroy(s) == 0
+    assert cd.od_ilqr_set_gradient_bundle(None, 5, eta.ctypes.data_as(C.c_void_p)) == -1
+    emu_lib.check(cd.od_ilqr_create(imc._h, 2, 4, 2, al, None, C.byref(s)))
+    eta = np.zeros((5, 8)); eta[0, :] = 1e-4
+    assert cd.od_ilqr_set_gradient_bundle(s, 8, eta.ctypes.data_as(C.c_void_p)) == 0
+    assert cd.od_ilqr_set_gradient_bundle(s, 4, eta.ctypes.data_as(C.c_void_p)) == 0      # fewer samples reuse the arrays
+    assert cd.od_ilqr_set_gradient_bundle(s, 8, None) == 0                                # NULL eta: implicit gradients again
     assert cd.od_ilqr_destroy(s) == 0
     # od_soc_project_full: empty batch is a no-op, null outputs are refused, a mechanical handle is unsupported
     u = torch.zeros(3, 4, dtype=torch.float64); z = torch.zeros(10, 4, dtype=torch.float64)

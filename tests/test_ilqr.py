@@ -280,6 +280,22 @@ def test_hopper_example_other_gaits_on_the_device_gpu(oracle, gpu_lib, gait):
     json.dump(st, open(os.path.join(d, "hopper_example_full_gait%d.json" % gait), "w"), indent=1)
 
 
+# ---- examples/planar_push.jl with GB = true: the gradient bundle as the solver's linearisation ---------------------------------------------------
+def test_gradient_bundle_linearisation_on_the_device_cpu(oracle, emu_lib):
+    C.check_bundle_linearisation(oracle, emu_lib, "cpu", mode="rotate", B=2, n_oracle=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["rotate", "translate"])
+def test_gradient_bundle_linearisation_on_the_device_gpu(oracle, gpu_lib, mode):
+    import json
+    import os
+    st = C.check_bundle_linearisation(oracle, gpu_lib, "cuda:0", mode=mode, B=32, n_oracle=2, need=0.9)
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    json.dump(st, open(os.path.join(d, "planar_push_gb_%s.json" % mode), "w"), indent=1)
+
+
 def test_constraint_generator_builds_a_new_constraint(tmp_path):
     """python -m optimization_dynamics_amd.codegen --add-constraint: a user's sympy constraint becomes device code (into a scratch root)"""
     import subprocess

@@ -22,9 +22,9 @@ def acrobot(B):
     return im, obj, np.zeros((4, B)), U0, T, dict(max_iter=50, max_al_iter=20, con_tol=1e-3, obj_tol=1e-5), tuple(2.0 ** -i for i in range(11))
 
 
-def run(name, make, B):
+def run(name, make, B, bundle=None):
     im, obj, x1, U0, T, opts, alphas = make(B)
-    sol = IL.ILQR(im, obj, T, alphas=alphas)
+    sol = IL.ILQR(im, obj, T, alphas=alphas, bundle=bundle)
     x1t, Ut = torch.tensor(x1, device=dev), torch.tensor(U0, device=dev)
     sol.solve(x1t, Ut, **dict(opts, max_iter=2, max_al_iter=1))        # buffers, lazy loads
     sol._dev = None
@@ -42,6 +42,11 @@ for B in (1, 64, 1024):
     run("cartpole frictionless (examples/cartpole.jl)", lambda b: (lambda r: (r[0], r[1], r[2], r[3], r[5], r[6], tuple(2.0 ** -i for i in range(17))))(C.cartpole_example(lib, dev, "frictionless", b)), B)
     for mode in ("rotate", "translate"):
         run("planar push %s (examples/planar_push.jl)" % mode, lambda b, mode=mode: (lambda r: (r[0], r[1], r[2], r[3], r[5], r[6], tuple(2.0 ** -i for i in range(17))))(C.planar_push_example(lib, dev, mode, b)), B)
+    from optimization_dynamics_amd import gradient_bundle as gbm
+    for mode in ("rotate", "translate"):
+        run("planar push %s with GB = true: GradientBundle N = 50 as the linearisation (examples/planar_push.jl:15, od_ilqr_set_gradient_bundle)" % mode,
+            lambda b, mode=mode: (lambda r: (r[0], r[1], r[2], r[3], r[5], r[6], tuple(2.0 ** -i for i in range(17))))(C.planar_push_example(lib, dev, mode, b)), B,
+            bundle=gbm.GradientBundle(od.planarpush, N=50, eps=1.0e-4, seed=3))
     run("cartpole with joint friction 0.35 (examples/cartpole.jl `:friction`)", lambda b: (lambda r: (r[0], r[1], r[2], r[3], r[5], r[6], tuple(2.0 ** -i for i in range(17))))(C.cartpole_example(lib, dev, "friction", b)), B)
     run("rocket landing AS SHIPPED (`:nominal`: thrust limits as stage constraints, no projection; examples/rocket.jl)",
         lambda b: (lambda r: (r[0], r[1], r[2], r[3], 60, r[5], r[6]))(C.rocket_example_nominal_problem(lib, dev, b)), B)
