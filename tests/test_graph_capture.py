@@ -146,3 +146,38 @@ def test_ilqr_iteration_with_parameter_stage_in_a_graph(gpu_lib):
         torch.cuda.synchronize()
     for a, b in zip(got, want):
         assert torch.equal(a, b)
+
+
+def test_ilqr_iteration_with_gradient_bundle_in_a_graph(gpu_lib):
+    """od_ilqr_set_gradient_bundle (examples/planar_push.jl with GB = true): the bundle's N + 1 steps per knot, the least-squares fit and
+    the scatter into fx / fu are kernels on the solver's stream like the rest -- one recorded iteration replayed n times == n direct ones"""
+    import ilqr_checks as C
+    import optimization_dynamics_amd as od
+    from optimization_dynamics_amd import gradient_bundle as gbm
+    B, n_it = 16, 6
+    im, obj, x1, U0, xT, T, opts = C.planar_push_example(gpu_lib, "cuda:0", "rotate", B)
+    gb = gbm.GradientBundle(od.planarpush, N=50, eps=1.0e-4, seed=3)
+    x1t, Ut = torch.tensor(x1, device="cuda:0"), torch.tensor(U0, device="cuda:0")
+    sol = od.ILQR(im, obj, T, bundle=gb)
+    direct = sol.device_solver(B, max_iter=n_it, obj_tol=0.0)
+    direct.init(x1t, Ut)
+    direct.iterate(n_it)
+    want = direct.get(gains=True) + (direct.history(),)
+    assert want[-1].shape[0] == n_it
+    rec = sol.device_solver(B, max_iter=n_it, obj_tol=0.0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        rec.init(x1t, Ut)
+        rec.iterate(1)
+        rec.init(x1t, Ut)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            rec.iterate(1)
+        for _ in range(n_it):
+            g.replay()
+        torch.cuda.synchronize()
+        got = rec.get(gains=True) + (rec.history(),)
+        torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
