@@ -732,12 +732,16 @@ def check_device_iteration(lib, device, problem="cartpole", B=6, T=15, dtype=tor
 
 
 # ---- od_ilqr_* against the INDEPENDENT numpy AL-iLQR of oracle/ilqr_np.py (driven by the oracle's dynamics), decision by decision ---------
-def acrobot_example(lib, device, B, T=100, h=0.05):
+def acrobot_example(lib, device, B, T=100, h=0.05, mode="impact"):
     """examples/acrobot.jl:15-111: swing-up, x1 = 0, x_T = [pi, 0, pi, 0] by augmented Lagrangian, 1/2 0.1 |v1|^2 + 1/2 u^2; trajectory b
-    starts from controls 1e-3 randn(seed 1 + b) (:90-91: trajectory 0 is the example's)"""
+    starts from controls 1e-3 randn(seed 1 + b) (:90-91: trajectory 0 is the example's).  mode "impact": joint limits (:19-23, kappa
+    1e-4 / 1e-3); "nominal": the mode the file ends up in (:11-12,24-27: acrobot_nominal, no joint limits, kappa = 1)"""
     import math
     import optimization_dynamics_amd as od
-    im = od.ImplicitDynamics(od.acrobot_impact, h, r_tol=1e-8, kappa_eval_tol=1e-4, kappa_grad_tol=1e-3, device=device, lib=lib)
+    if mode == "impact":
+        im = od.ImplicitDynamics(od.acrobot_impact, h, r_tol=1e-8, kappa_eval_tol=1e-4, kappa_grad_tol=1e-3, device=device, lib=lib)
+    else:
+        im = od.ImplicitDynamics(od.acrobot_nominal, h, r_tol=1e-8, kappa_eval_tol=1.0, kappa_grad_tol=1.0, device=device, lib=lib)
     I2 = np.eye(2)
     Q = 0.1 / h ** 2 * np.block([[I2, -I2], [-I2, I2]])
     xT = np.array([math.pi, 0.0, math.pi, 0.0])
@@ -753,6 +757,8 @@ ORACLE_CASES = {
     # the swing-up passes through joint-limit impacts: a contact-mode switch amplifies the 1e-12 between two implementations of one
     # solve to 1e-5 in a later cost (both stay valid solves of the task: same outcome)
     "acrobot": dict(T=100, kw=dict(max_iter=50, max_al_iter=20, obj_tol=1e-5, con_tol=1e-3), tolJ=1e-8, need=30),
+    # examples/acrobot.jl AS SHIPPED (`:nominal`: no joint limits, smooth dynamics)
+    "acrobot_nominal": dict(T=100, kw=dict(max_iter=50, max_al_iter=20, obj_tol=1e-5, con_tol=1e-3), tolJ=1e-8, need=None),
     "rocket": dict(T=20, kw=dict(max_iter=10, max_al_iter=1, obj_tol=1e-7, con_tol=1e-4), tolJ=1e-8, need=None),
     # with the thrust-cone projection on the path every control is a kappa_tol = 1e-4 accurate end point of a line search that
     # compares rounding noise (parity_checks.check_rocket_sweep): costs agree to that level until an Armijo test lands on the other side
@@ -778,6 +784,9 @@ def check_against_numpy_oracle(oracle, lib, device, case, B=8, seed=1):
     elif case == "acrobot":
         im, obj, x1, U0 = acrobot_example(lib, device, B, T)
         step, lin = N.mechanical_dynamics(oracle.make_sim("acrobot_impact", 0.05, kappa_tol=1e-4, kappa_grad_tol=1e-3))
+    elif case == "acrobot_nominal":
+        im, obj, x1, U0 = acrobot_example(lib, device, B, T, mode="nominal")
+        step, lin = N.mechanical_dynamics(oracle.make_sim("acrobot_nominal", 0.05, kappa_tol=1.0, kappa_grad_tol=1.0))
     else:
         im, obj, x1, U0 = rocket_problem(lib, device, B, T, seed=seed)
         if case == "rocket":

@@ -228,6 +228,12 @@ def test_acrobot_solver_decisions_against_the_numpy_oracle_cpu(oracle, emu_lib):
     C.check_against_numpy_oracle(oracle, emu_lib, "cpu", "acrobot", B=1)
 
 
+def test_acrobot_as_shipped_solver_decisions_against_the_numpy_oracle_cpu(oracle, emu_lib):
+    """examples/acrobot.jl in the mode the file ends up in (`:nominal`, :11-12: no joint limits): every decision of all ~300 iterations"""
+    st = C.check_against_numpy_oracle(oracle, emu_lib, "cpu", "acrobot_nominal", B=1)
+    assert st["agreeing_iterations"] == st["iterations_oracle"] and st["iterations_oracle"][0] > 100
+
+
 @pytest.mark.gpu
 def test_solver_decisions_against_the_numpy_oracle_gpu(oracle, gpu_lib):
     """cartpole with two augmented-Lagrangian rounds, the constrained cartpole (stage and terminal rows), the acrobot swing-up of
@@ -235,7 +241,7 @@ def test_solver_decisions_against_the_numpy_oracle_gpu(oracle, gpu_lib):
     step index, regularisation, penalty and cost of every iteration, final trajectory and flags; gpurun_out/ilqr_oracle_parity.json"""
     import json
     import os
-    out = [C.check_against_numpy_oracle(oracle, gpu_lib, "cuda:0", case, B=8) for case in ("cartpole", "cartpole_constrained", "acrobot", "rocket", "rocket_projected")]
+    out = [C.check_against_numpy_oracle(oracle, gpu_lib, "cuda:0", case, B=8) for case in ("cartpole", "cartpole_constrained", "acrobot", "acrobot_nominal", "rocket", "rocket_projected")]
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(d, exist_ok=True)
     json.dump(out, open(os.path.join(d, "ilqr_oracle_parity.json"), "w"), indent=1)

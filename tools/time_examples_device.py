@@ -12,9 +12,12 @@ lib = od.default_library(); dev = "cuda:0"
 out = {}
 
 
-def acrobot(B):
+def acrobot(B, mode="impact"):
     h, T = 0.05, 100
-    im = od.ImplicitDynamics(od.acrobot_impact, h, r_tol=1e-8, kappa_eval_tol=1e-4, kappa_grad_tol=1e-3, device=dev, lib=lib)
+    if mode == "impact":
+        im = od.ImplicitDynamics(od.acrobot_impact, h, r_tol=1e-8, kappa_eval_tol=1e-4, kappa_grad_tol=1e-3, device=dev, lib=lib)
+    else:
+        im = od.ImplicitDynamics(od.acrobot_nominal, h, r_tol=1e-8, kappa_eval_tol=1.0, kappa_grad_tol=1.0, device=dev, lib=lib)
     I2 = np.eye(2); Q = 0.1 / h ** 2 * np.block([[I2, -I2], [-I2, I2]])
     xT = np.array([math.pi, 0.0, math.pi, 0.0])
     obj = IL.QuadraticObjective(Q, np.eye(1), Q, x_ref=np.zeros(4), goal_idx=[0, 1, 2, 3], goal=xT, device=dev)
@@ -39,6 +42,7 @@ def run(name, make, B, bundle=None):
 
 for B in (1, 64, 1024):
     run("acrobot swing-up (examples/acrobot.jl)", acrobot, B)
+    run("acrobot swing-up AS SHIPPED (`:nominal`: no joint limits; examples/acrobot.jl:11-12)", lambda b: acrobot(b, "nominal"), B)
     run("cartpole frictionless (examples/cartpole.jl)", lambda b: (lambda r: (r[0], r[1], r[2], r[3], r[5], r[6], tuple(2.0 ** -i for i in range(17))))(C.cartpole_example(lib, dev, "frictionless", b)), B)
     for mode in ("rotate", "translate"):
         run("planar push %s (examples/planar_push.jl)" % mode, lambda b, mode=mode: (lambda r: (r[0], r[1], r[2], r[3], r[5], r[6], tuple(2.0 ** -i for i in range(17))))(C.planar_push_example(lib, dev, mode, b)), B)
