@@ -175,11 +175,14 @@ end
 # From consecutive columns the accepted step size of iteration k follows (u_k - u_{k-1} against the feed-forward direction), the
 # cost decrease is there directly.  Only call sites the reference's own example makes are used (examples/acrobot.jl:33-37,74-76,
 # 85-87,92,97-121); if the installed IterativeLQR differs, the block is skipped with a note.
+# Both modes of the file: `:impact` (joint limits; prefix acrobot_ilqr) and `:nominal` (:11-12, what the file ends up in: no contact,
+# smooth dynamics -- two correct implementations of one rule set should not part at all there; prefix acrobot_nominal_ilqr).
+for (prefix, mdl, rf, rzf, rθf, κe, κg) in (("acrobot_ilqr", acrobot_impact, r_acrobot_impact_func, rz_acrobot_impact_func, rθ_acrobot_impact_func, 1.0e-4, 1.0e-3),
+                                              ("acrobot_nominal_ilqr", acrobot_nominal, r_acrobot_nominal_func, rz_acrobot_nominal_func, rθ_acrobot_nominal_func, 1.0, 1.0))
 try
     iLQR = OptimizationDynamics.IterativeLQR
     h = 0.05; T = 101
-    im_dyn = ImplicitDynamics(acrobot_impact, h, eval(r_acrobot_impact_func), eval(rz_acrobot_impact_func), eval(rθ_acrobot_impact_func);
-        r_tol=1.0e-8, κ_eval_tol=1.0e-4, κ_grad_tol=1.0e-3, no_friction=true)
+    im_dyn = ImplicitDynamics(mdl, h, eval(rf), eval(rzf), eval(rθf); r_tol=1.0e-8, κ_eval_tol=κe, κ_grad_tol=κg, no_friction=true)
     nx = 2 * acrobot_impact.nq; nu = acrobot_impact.nu
     ilqr_dyn = iLQR.Dynamics((d, x, u, w) -> f(d, im_dyn, x, u, w), (dx, x, u, w) -> fx(dx, im_dyn, x, u, w),
                              (du, x, u, w) -> fu(du, im_dyn, x, u, w), nx, nx, nu)
@@ -192,7 +195,7 @@ try
     cons = [[iLQR.Constraint() for t = 1:T-1]..., iLQR.Constraint(terminal_con, nx, 0)]
     Random.seed!(1)
     ū = [1.0e-3 * randn(nu) for t = 1:T-1]
-    writearr(joinpath(outdir, "acrobot_ilqr_U0.bin"), reshape(vcat(ū...), 1, T - 1))
+    writearr(joinpath(outdir, prefix * "_U0.bin"), reshape(vcat(ū...), 1, T - 1))
     function run(max_iter, max_al_iter)
         x̄ = iLQR.rollout(model, x1, ū)
         solver = iLQR.solver(model, obj, cons, opts=iLQR.Options(linesearch=:armijo, α_min=1.0e-5, obj_tol=1.0e-5, grad_tol=1.0e-5,
@@ -211,11 +214,12 @@ try
         it, J, M, v, u = run(k, 1)
         TR[:, k] = [k, it, J, M, v]; UU[1, :, k] = u
     end
-    writearr(joinpath(outdir, "acrobot_ilqr_trace.bin"), TR)
-    writearr(joinpath(outdir, "acrobot_ilqr_U.bin"), UU)
+    writearr(joinpath(outdir, prefix * "_trace.bin"), TR)
+    writearr(joinpath(outdir, prefix * "_U.bin"), UU)
     it, J, M, v, u = run(50, 20)
-    writearr(joinpath(outdir, "acrobot_ilqr_full.bin"), reshape([it, J, M, v], 4, 1))
+    writearr(joinpath(outdir, prefix * "_full.bin"), reshape([it, J, M, v], 4, 1))
 catch e
-    println("acrobot iLQR trace not written: ", e)
+    println(prefix, ": iLQR trace not written: ", e)
+end
 end
 println("reference vectors written to ", outdir)

@@ -206,23 +206,28 @@ def test_projection_iterate_path_matches_julia_reference(oracle, emu_lib):
 
 
 @have_ref
-def test_ilqr_iterations_match_julia_reference(oracle):
+@pytest.mark.parametrize("mode", ["impact", "nominal"])
+def test_ilqr_iterations_match_julia_reference(oracle, mode):
     """acrobot_ilqr_trace.bin / acrobot_ilqr_U0.bin (oracle/gen_golden.jl): IterativeLQR's solve! on examples/acrobot.jl cut short after
     k = 1..30 iterations of its first augmented-Lagrangian round.  The numpy AL-iLQR of oracle/ilqr_np.py (the checker of od_ilqr_*)
     run from the same initial controls must produce the same objective after the same number of iterations -- this is what pins the
     recalled rules of IterativeLQR (regularisation schedule, Armijo constant, step sizes, expansion) one iteration at a time; the first k
     at which they part names the rule that differs (up to the chaotic growth of contact problems: asserted for the first 10)."""
-    if not os.path.exists(os.path.join(REF, "acrobot_ilqr_trace.bin")):
-        pytest.skip("no iLQR trace in this set of vectors")
+    prefix = "acrobot_ilqr" if mode == "impact" else "acrobot_nominal_ilqr"      # (`:nominal`: what examples/acrobot.jl:11-12 ends up in)
+    if not os.path.exists(os.path.join(REF, prefix + "_trace.bin")):
+        pytest.skip("no iLQR trace of this mode in this set of vectors")
     import math
     from oracle import ilqr_np as N
-    TR = ref("acrobot_ilqr_trace", (5, 30))
-    U0 = ref("acrobot_ilqr_U0", (1, 100))
+    TR = ref(prefix + "_trace", (5, 30))
+    U0 = ref(prefix + "_U0", (1, 100))
     h = 0.05
     I2 = np.eye(2)
     Q = 0.1 / h ** 2 * np.block([[I2, -I2], [-I2, I2]])
     xT = np.array([math.pi, 0.0, math.pi, 0.0])
-    step, lin = N.mechanical_dynamics(oracle.make_sim("acrobot_impact", h, kappa_tol=1e-4, kappa_grad_tol=1e-3))
+    if mode == "impact":
+        step, lin = N.mechanical_dynamics(oracle.make_sim("acrobot_impact", h, kappa_tol=1e-4, kappa_grad_tol=1e-3))
+    else:
+        step, lin = N.mechanical_dynamics(oracle.make_sim("acrobot_nominal", h, kappa_tol=1.0, kappa_grad_tol=1.0))
     p = N.Problem(step, lin, Q, np.eye(1), Q, np.zeros(4), goal_idx=[0, 1, 2, 3], goal=xT)
     r = N.solve(p, np.zeros(4), U0.T, max_iter=30, max_al_iter=1, obj_tol=1e-5, con_tol=1e-3)
     plain = N.Problem(step, lin, Q, np.eye(1), Q, np.zeros(4))
@@ -234,7 +239,8 @@ def test_ilqr_iterations_match_julia_reference(oracle):
             first = (k + 1, e)
     if first is not None:
         print("iLQR history parts from the reference at iteration %d (relative %.2e)" % first)
-    assert first is None or first[0] > 10, first
+    # (without contact nothing amplifies: device solver and numpy oracle agree on all 303 iterations of this mode, profiles/r5_ilqr_oracle_parity.json)
+    assert first is None or (mode == "impact" and first[0] > 10), first
 
 
 @have_ref
