@@ -260,10 +260,12 @@ OD_HD double od_il_next_reg(double r) { return fmin(fmax(r, 1e-8) * 10.0, 1e6); 
 // indexed private arrays (scratch): 53 ms per call for the rocket (n = 12, m = 3, T = 60, 4096 trajectories) -- 77 % of an
 // iLQR iteration; this one: see profiles/r1_ilqr.json.
 constexpr int OD_IL_THREADS = 256;
-template <class TA> __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward(IlqrArgsT<TA> a) {
+// (NC, MC: the sizes as compile-time constants -- the substitution's right-hand side y[] then lives in registers instead of scratch
+// memory and the loops over m unroll: the parameter stage's embedded model, od_ilqr_solver.inc::ilp_backward; 0, 0: any size)
+template <class TA, int NC = 0, int MC = 0> __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_backward(IlqrArgsT<TA> a) {
   if (a.skip && *a.skip) return;
   const long b = blockIdx.x;
-  const int n = a.n, m = a.m, tid = threadIdx.x;
+  const int n = NC ? NC : a.n, m = NC ? MC : a.m, tid = threadIdx.x;
   __shared__ double Vxx[OD_IL_N * OD_IL_N], At[OD_IL_N * OD_IL_N], W[OD_IL_N * OD_IL_N], Qxx[OD_IL_N * OD_IL_N];
   __shared__ double Bt[OD_IL_N * OD_IL_M], WB[OD_IL_N * OD_IL_M], Qux[OD_IL_M * OD_IL_N], Kt[OD_IL_M * OD_IL_N], QK[OD_IL_M * OD_IL_N];
   __shared__ double Quu[OD_IL_M * OD_IL_M], L[OD_IL_M * OD_IL_M];
@@ -315,11 +317,25 @@ template <class TA> __global__ __launch_bounds__(OD_IL_THREADS) void k_ilqr_back
     // K = -(Quu+reg)^{-1} Qux (one thread per column), k = -(Quu+reg)^{-1} Qu (thread n)
     if (tid <= n) {
       const int c = tid;
-      double y[OD_IL_M];
-      for (int i = 0; i < m; ++i) y[i] = (c < n) ? Qux[i + m * c] : Qu[i];
-      for (int i = 0; i < m; ++i) { double sx = y[i]; for (int l = 0; l < i; ++l) sx -= L[i + m * l] * y[l]; y[i] = sx / L[i + m * i]; }
-      for (int i = m - 1; i >= 0; --i) { double sx = y[i]; for (int l = i + 1; l < m; ++l) sx -= L[l + m * i] * y[l]; y[i] = sx / L[i + m * i]; }
-      for (int i = 0; i < m; ++i) { if (c < n) Kt[i + m * c] = -y[i]; else kt[i] = -y[i]; }
+      double y[MC ? MC : OD_IL_M];
+#pragma unroll
+      for (int i = 0; i < (MC ? MC : m); ++i) y[i] = (c < n) ? Qux[i + m * c] : Qu[i];
+#pragma unroll
+      for (int i = 0; i < (MC ? MC : m); ++i) {
+        double sx = y[i];
+#pragma unroll
+        for (int l = 0; l < i; ++l) sx -= L[i + m * l] * y[l];
+        y[i] = sx / L[i + m * i];
+      }
+#pragma unroll
+      for (int i = (MC ? MC : m) - 1; i >= 0; --i) {
+        double sx = y[i];
+#pragma unroll
+        for (int l = i + 1; l < (MC ? MC : m); ++l) sx -= L[l + m * i] * y[l];
+        y[i] = sx / L[i + m * i];
+      }
+#pragma unroll
+      for (int i = 0; i < (MC ? MC : m); ++i) { if (c < n) Kt[i + m * c] = -y[i]; else kt[i] = -y[i]; }
     }
     __syncthreads();
     if (tid < nm) a.K.at(tid, kk) = (TA)Kt[tid];
