@@ -1733,7 +1733,7 @@ int od_rollout_policy(od_handle h, long B, int T, int nalpha, const void* alphas
   pa.K = mkcview<double>(K, nu * n, Kn, L);
   pa.kff = mkcview<double>(kff, nu, Kn, L);
   pa.U = mkview<double>(U, nu, Kc, L);
-  pa.skip = nullptr; pa.live = nullptr; pa.live_mod = 1;
+  pa.skip = nullptr; pa.live = nullptr; pa.live_mod = 1; pa.stop_failed = 0;
   OD_HIP(h->vt->rollout_policy(pa, cfg_of(h, P), h->stream));
   return OD_OK;
 }

@@ -831,8 +831,8 @@ struct CoopNoHook { OD_HD void operator()() const {} };
 // while the only memory operations in flight are a knot old (the wait counter is in order: after the stores it would
 // wait for them as well, one store round trip per knot)
 template <class CM, class RO, class Hook = CoopNoHook>
-OD_HD void coop_knot_state(const CoopLanes<CM, RO>& L0, const StepArgs<double>& a, long k, const double* xin, const double* uin, double* q3out,
-                           const Hook& before_stores = Hook()) {
+OD_HD int coop_knot_state(const CoopLanes<CM, RO>& L0, const StepArgs<double>& a, long k, const double* xin, const double* uin, double* q3out,
+                          const Hook& before_stores = Hook()) {
   using M = typename CM::M;
   using V = typename RO::V;
   constexpr int nq = M::NQ;
@@ -872,6 +872,7 @@ OD_HD void coop_knot_state(const CoopLanes<CM, RO>& L0, const StepArgs<double>& 
       if (a.iters.ok()) { auto c = a.iters.cursor(k); c.put(it[0]); c.put(it[1]); }
     }
   }
+  return st;                    // (the same in every lane of the row: the solve's exits are row decisions)
 }
 
 template <class CM, class RO> OD_HD void coop_unit_step_state(const StepArgs<double>& a, long b) {
@@ -1100,7 +1101,11 @@ template <class CM, class RO> OD_HD void coop_unit_rollout_policy(const PolicyAr
 #pragma unroll
       for (int j = 0; j < M::NU; ++j) pa.U.at(j, kc) = u[j];
     }
-    coop_knot_state<CM, RO>(L, a, kc, x, u, q3);
+    const int st = coop_knot_state<CM, RO>(L, a, kc, x, u, q3);
+    if (pa.stop_failed && !(st & OD_ST_EVAL_OK)) {          // (PolicyArgs::stop_failed; the whole row leaves, like a row past the batch)
+      if (RO::first_lane()) policy_mark_rest_failed(pa, t, p);
+      break;
+    }
 #pragma unroll
     for (int i = 0; i < nq; ++i) { x[i] = x[nq + i]; x[nq + i] = q3[i]; }
   }

@@ -888,8 +888,8 @@ template <class CM, class RO> OD_HD void c3_init_z(const double* z0, C3Vec<CM::N
 
 struct C3NoHook { OD_HD void operator()() const {} };
 template <class CM, class RO, class Hook = C3NoHook>
-OD_HD void c3_knot_state(const C3Lanes<CM, RO>& L0, const StepArgs<double>& a, long k, const double* xin, const double* uin, double* q3out,
-                         const Hook& before_stores = Hook()) {
+OD_HD int c3_knot_state(const C3Lanes<CM, RO>& L0, const StepArgs<double>& a, long k, const double* xin, const double* uin, double* q3out,
+                        const Hook& before_stores = Hook()) {
   using M = typename CM::M;
   using V = typename RO::V;
   constexpr int nq = M::NQ;
@@ -926,6 +926,7 @@ OD_HD void c3_knot_state(const C3Lanes<CM, RO>& L0, const StepArgs<double>& a, l
       if (a.iters.ok()) { auto c = a.iters.cursor(k); c.put(it[0]); c.put(it[1]); }
     }
   }
+  return st;
 }
 
 template <class CM, class RO> OD_HD void c3_unit_step_state(const StepArgs<double>& a, long b) {
@@ -1005,7 +1006,11 @@ template <class CM, class RO> OD_HD void c3_unit_rollout_policy(const PolicyArgs
 #pragma unroll
       for (int j = 0; j < M::NU; ++j) pa.U.at(j, kc) = u[j];
     }
-    c3_knot_state<CM, RO>(L, a, kc, x, u, q3);
+    const int st = c3_knot_state<CM, RO>(L, a, kc, x, u, q3);
+    if (pa.stop_failed && !(st & OD_ST_EVAL_OK)) {          // (PolicyArgs::stop_failed; the whole group leaves)
+      if (RO::first_lane()) policy_mark_rest_failed(pa, t, p);
+      break;
+    }
 #pragma unroll
     for (int i = 0; i < nq; ++i) { x[i] = x[nq + i]; x[nq + i] = q3[i]; }
   }

@@ -154,7 +154,7 @@ template <class M, class T> struct DeferSink {
 
 // pass 1 for one knot k given its state and control in registers; returns q3 in q3out
 template <class M, class T, class Store = RegFactStore<M, T>>
-OD_HD void knot_state(const StepArgs<T>& a, long k, const T* xin, const T* uin, T* q3out) {
+OD_HD int knot_state(const StepArgs<T>& a, long k, const T* xin, const T* uin, T* q3out) {
   constexpr int nq = M::NQ;
   T th[M::NTH], z[M::NZ];
   mech_setup<M>(xin, xin + nq, uin, a.fric, a.h, th, z);
@@ -184,6 +184,7 @@ OD_HD void knot_state(const StepArgs<T>& a, long k, const T* xin, const T* uin, 
     if (a.status.ok()) a.status.at(0, k) = st;
     if (a.iters.ok()) { auto c = a.iters.cursor(k); c.put(it[0]); c.put(it[1]); }
   }
+  return st;
 }
 
 // independent knots (od_step, od_step_grad pass 1)
@@ -255,7 +256,17 @@ template <class T> struct PolicyArgs {
   const int* skip;       // device flag (may be null): non-zero = the launch does nothing (device-resident iLQR iteration, od_ilqr_solver.inc)
   const int* live;       // (may be null) per nominal trajectory: candidate p is rolled out only if live[p % live_mod] != 0
   long live_mod;
+  int stop_failed;       // non-zero (the forward pass of od_ilqr_*): a candidate ends at its first knot whose solve did not converge; the
+                         // status of its remaining knots is written as 0, their states and controls are left as they were.  The Armijo
+                         // selection takes only rollouts whose every knot converged (k_il_select), so the rest of such a rollout is never
+                         // looked at -- and a diverged candidate would otherwise keep its wavefront waiting for a 100-iteration solve at
+                         // every remaining knot.  0 (od_rollout_policy): every knot of every candidate, as asked
 };
+// (shared by the three forms of the kernel: the candidate's remaining knots are marked not converged)
+template <class T> OD_HD void policy_mark_rest_failed(const PolicyArgs<T>& pa, int t, long p) {
+  const StepArgs<T>& a = pa.r.s;
+  if (a.status.ok()) for (int t2 = t + 1; t2 < pa.r.Tn; ++t2) a.status.at(0, (long)t2 * a.B + p) = 0;
+}
 
 template <class M, class T> OD_HD void unit_rollout_policy(const PolicyArgs<T>& pa, long p) {
   constexpr int nq = M::NQ, n = 2 * M::NQ, nu = M::NU > 0 ? M::NU : 1;
@@ -292,7 +303,8 @@ template <class M, class T> OD_HD void unit_rollout_policy(const PolicyArgs<T>& 
 #pragma unroll
       for (int j = 0; j < M::NU; ++j) co.put(u[j]);
     }
-    knot_state<M, T>(a, kc, x, u, q3);
+    const int st = knot_state<M, T>(a, kc, x, u, q3);
+    if (pa.stop_failed && !(st & OD_ST_EVAL_OK)) { policy_mark_rest_failed(pa, t, p); break; }
 #pragma unroll
     for (int i = 0; i < nq; ++i) { x[i] = x[nq + i]; x[nq + i] = q3[i]; }
   }

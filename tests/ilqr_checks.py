@@ -731,6 +731,37 @@ def check_device_iteration(lib, device, problem="cartpole", B=6, T=15, dtype=tor
     return got, ref
 
 
+def check_forward_pass_early_exit(lib, device, B=4, max_iter=6, scale=300.0):
+    """the solver's forward pass ends a candidate at its first knot whose solve fails (PolicyArgs::stop_failed) -- such a rollout can
+    never be accepted.  The cartpole with joint friction (examples/cartpole.jl `:friction`) started from wild controls (|u| ~ 300): the
+    first policies throw the large step sizes into states whose solves do not converge.  od_ilqr_solve must reproduce, cost by cost,
+    the loop composed on the host from od_rollout_policy, which rolls every candidate out to its horizon; and the first policy really
+    has such candidates (counted with the public entry point).  -> their number"""
+    im, obj, x1, U0, xT, T, opts = cartpole_example(lib, device, "friction", B)
+    U0 = scale * np.random.default_rng(5).normal(size=U0.shape)
+    kw = dict(opts, max_iter=max_iter, max_al_iter=1)
+    x1t, Ut = torch.tensor(x1, device=device), torch.tensor(U0, device=device)
+    alphas = tuple(2.0 ** -i for i in range(11))
+    ref = IL.ILQR(im, obj, T, alphas=alphas).solve_stepwise(x1t, Ut, **kw)
+    sol = IL.ILQR(im, obj, T, alphas=alphas)
+    got = sol.solve(x1t, Ut, **kw)
+    assert len(got[3]) == len(ref[3]) == sol._dev.info().iterations
+    for i, (ja, jb) in enumerate(zip(got[3], ref[3])):
+        assert ((ja - jb).abs() <= 1e-9 * jb.abs().clamp(min=1.0)).all(), (i, (ja - jb).abs().max().item())
+    sc = max(1.0, ref[0].abs().max().item())
+    assert (got[0] - ref[0]).abs().max().item() < 1e-6 * sc and (got[1] - ref[1]).abs().max().item() < 1e-6 * scale
+    # the first policy of the solve, rolled out in full through the public entry point: how many candidates have a failed knot
+    d = sol.device_solver(B, max_iter=1, obj_tol=0.0)
+    d.init(x1t, Ut)
+    X0 = d.get()[0].clone()
+    d.iterate(1)
+    K, k = d.get(gains=True)[3:]
+    Xc, Uc, cst = sol.forward(x1t, X0, Ut, K, k)
+    nbad = int(((cst & 1) == 0).any(0).sum().item())
+    assert nbad > 0, "no candidate of the first forward pass has a failed knot: the check does not exercise the early exit"
+    return nbad
+
+
 # ---- od_ilqr_* against the INDEPENDENT numpy AL-iLQR of oracle/ilqr_np.py (driven by the oracle's dynamics), decision by decision ---------
 def acrobot_example(lib, device, B, T=100, h=0.05, mode="impact"):
     """examples/acrobot.jl:15-111: swing-up, x1 = 0, x_T = [pi, 0, pi, 0] by augmented Lagrangian, 1/2 0.1 |v1|^2 + 1/2 u^2; trajectory b

@@ -288,6 +288,16 @@ def test_hopper_example_other_gaits_on_the_device_gpu(oracle, gpu_lib, gait):
     json.dump(st, open(os.path.join(d, "hopper_example_full_gait%d.json" % gait), "w"), indent=1)
 
 
+# ---- the forward pass leaves a candidate at its first failed knot ----------------------------------------------------------------------------------
+def test_forward_pass_early_exit_cpu(emu_lib):
+    assert C.check_forward_pass_early_exit(emu_lib, "cpu") > 0
+
+
+@pytest.mark.gpu
+def test_forward_pass_early_exit_gpu(gpu_lib):
+    assert C.check_forward_pass_early_exit(gpu_lib, "cuda:0", B=64) > 0
+
+
 # ---- examples/planar_push.jl with GB = true: the gradient bundle as the solver's linearisation ---------------------------------------------------
 def test_gradient_bundle_linearisation_on_the_device_cpu(oracle, emu_lib):
     C.check_bundle_linearisation(oracle, emu_lib, "cpu", mode="rotate", B=2, n_oracle=1)
