@@ -357,6 +357,12 @@ template <class T> struct BundleArgs {
   const T* eta;           // (2nq+nu) x N col-major, shared by all knots
   View<T> feta;           // nq per problem p
   View<int> status;       // per problem p
+  // device-resident iLQR with the bundle as linearisation (od_ilqr_solver.inc): skip non-zero = the launch does nothing; the samples of
+  // knot k are computed only if live[k % live_mod] != 0 (the trajectory took a step: the others' samples stand as they are).  Null otherwise.
+  const int* skip = nullptr;
+  const int* live = nullptr;
+  long live_mod = 1;
+  OD_HD bool dead(long p) const { return live && !live[(p / (N + 1)) % live_mod]; }
 };
 
 template <class M, class T, class Store = RegFactStore<M, T>> OD_HD void unit_bundle_sample(const BundleArgs<T>& ba, long p) {
