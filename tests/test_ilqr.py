@@ -238,11 +238,11 @@ def test_acrobot_as_shipped_solver_decisions_against_the_numpy_oracle_cpu(oracle
 def test_solver_decisions_against_the_numpy_oracle_gpu(oracle, gpu_lib):
     """cartpole with two augmented-Lagrangian rounds, the constrained cartpole (stage and terminal rows), the acrobot swing-up of
     examples/acrobot.jl (with joint limits, and `:nominal` as the file ships: all 303 iterations) and the rocket in double precision
-    (with and without the thrust-cone projection), 8 problems each (4 for `:nominal`): accepted
+    (with and without the thrust-cone projection), 8 problems each (2 for `:nominal` in this test): accepted
     step index, regularisation, penalty and cost of every iteration, final trajectory and flags; gpurun_out/ilqr_oracle_parity.json"""
     import json
     import os
-    out = [C.check_against_numpy_oracle(oracle, gpu_lib, "cuda:0", case, B=(4 if case == "acrobot_nominal" else 8))       # (303 iterations of numpy per problem)
+    out = [C.check_against_numpy_oracle(oracle, gpu_lib, "cuda:0", case, B=(2 if case == "acrobot_nominal" else 8))       # (303 iterations of numpy per problem; 8 problems: profiles/r5_ilqr_oracle_parity_acrobot_nominal_8.json)
            for case in ("cartpole", "cartpole_constrained", "acrobot", "acrobot_nominal", "rocket", "rocket_projected")]
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(d, exist_ok=True)
