@@ -239,7 +239,7 @@ def test_ilqr_iterations_match_julia_reference(oracle, mode):
             first = (k + 1, e)
     if first is not None:
         print("iLQR history parts from the reference at iteration %d (relative %.2e)" % first)
-    # (without contact nothing amplifies: device solver and numpy oracle agree on all 303 iterations of this mode, profiles/r5_ilqr_oracle_parity.json)
+    # (without contact nothing amplifies: device solver and numpy oracle agree on all 303 iterations of this mode, profiles/r5_ilqr_oracle_parity_acrobot_nominal_8.json)
     assert first is None or (mode == "impact" and first[0] > 10), first
 
 
