@@ -875,6 +875,70 @@ def check_rollout_instantiation(oracle, lib, device, B, T, B_ref, n_oracle=256, 
     return im
 
 
+def check_solutions_against_hand_written_residuals(oracle, lib, device, name, B=2048, seed=11):
+    """The device's model code and the oracle's are generated from one symbolic specification; the second source is
+    oracle/models_np.py, the residuals of src/models/<model>/model.jl restated by hand in numpy (tests/test_models.py holds the
+    generated code to it at random points on the CPU).  Here the DEVICE's own answers are held to it: at every converged solution z
+    of od_step_full, with theta = [q1; q2; u; friction; h] as RoboDojo.step! assembles it,
+      * the hand-written residual equals the generated one row by row (1e-12), at kappa = 0 and at kappa_eval_tol -- so
+      * the loop's own stopping test, evaluated at the device's z, is a statement about the hand-written model: equality rows
+        below r_tol, complementarity rows below kappa_eval_tol.
+    -> statistics"""
+    from oracle import models_np as NP
+    h, ke, kg, fric = W.CONFIGS[name]
+    im = make_im(name, lib, device)
+    X, U = W.knots(name, B, seed=seed)
+    Z, _, st, it = im.step_full(torch.tensor(X, device=device), torch.tensor(U, device=device), grads=False)
+    Z, st = Z.cpu().numpy(), st.cpu().numpy()
+    nq = X.shape[0] // 2
+    mu = np.asarray(im.model.friction, dtype=np.float64).reshape(-1)
+    ok = (st & 1) == 1
+    assert ok.mean() > 0.9, ok.mean()
+    TH = np.concatenate([X[nq:] - h * ((X[nq:] - X[:nq]) / h), X[nq:], U, np.repeat(mu[:, None], B, 1), np.full((1, B), h)], axis=0)
+    f = NP.RESIDUALS[name]
+    worst = 0.0
+    for b in np.nonzero(ok)[0][:: max(1, int(ok.sum()) // 512)]:           # (python loop: up to 512 of the converged knots)
+        for kap in (0.0, ke):
+            rn = f(Z[:, b], TH[:, b], kap)
+            rg = oracle.eval_r(name, Z[:, b], TH[:, b], kap)
+            worst = max(worst, float(np.abs(rn - rg).max() / max(1.0, np.abs(rn).max())))
+    assert worst < 1e-12, (name, worst)
+    rv, kv = oracle.violations_batch(name, Z[:, ok], TH[:, ok])
+    assert rv.max() < 1.0e-8 and kv.max() < ke, (name, float(rv.max()), float(kv.max()))
+    return dict(model=name, knots=int(B), converged=int(ok.sum()), hand_written_vs_generated_rel_max=worst,
+                equality_rows_max=float(rv.max()), complementarity_rows_max=float(kv.max()), kappa_eval_tol=ke)
+
+
+def check_rocket_solutions_against_hand_written_residuals(oracle, lib, device, B=2048, seed=11, u_max=12.5, h=0.05):
+    """the same for the rocket's two models (src/models/rocket/model.jl, codegen.jl restated by hand in oracle/models_np.py): the
+    projection's whole solution (od_soc_project_full, theta = [u; u_max]) and the dynamics step (od_rocket without projection: z is
+    the next state, theta = [x; u; h]) -- hand-written == generated at the device's solutions, stopping test on the converged ones"""
+    from oracle import models_np as NP
+    from optimization_dynamics_amd import rocket as rk
+    info = rk.RocketInfo(models.rocket, u_max, h, device=device, lib=lib)
+    X, U = W.rocket_inputs(B, seed=seed)
+    out = {}
+    Zp, _, stp, _ = info.project_full(torch.tensor(U, device=device), grads=False)
+    Y, _, _, _, std = info.solve(torch.tensor(X, device=device), torch.tensor(U, device=device), project=False, grads=False)
+    cases = (("rocket_projection", Zp.double().cpu().numpy(), np.vstack([U, np.full((1, B), u_max)]), (stp.cpu().numpy() & 0x10) == 0x10, 1e-4),
+             ("rocket_dynamics", Y.double().cpu().numpy(), np.vstack([X, U, np.full((1, B), h)]), (std.cpu().numpy() & 1) == 1, None))
+    for name, Z, TH, ok, ktol in cases:
+        assert ok.mean() > 0.9, (name, ok.mean())
+        f = NP.RESIDUALS[name]
+        worst = 0.0
+        for b in np.nonzero(ok)[0][:: max(1, int(ok.sum()) // 512)]:
+            for kap in (0.0, 1e-4):
+                rn = f(Z[:, b], TH[:, b], kap)
+                rg = oracle.eval_r(name, Z[:, b], TH[:, b], kap)
+                worst = max(worst, float(np.abs(rn - rg).max() / max(1.0, np.abs(rn).max())))
+        assert worst < 1e-12, (name, worst)
+        rv, kv = oracle.violations_batch(name, Z[:, ok], TH[:, ok])
+        assert rv.max() < 1.0e-8 and (ktol is None or kv.max() < ktol * (1.0 + 1e-9)), (name, float(rv.max()), float(kv.max()))
+        out[name] = dict(knots=int(B), converged=int(ok.sum()), hand_written_vs_generated_rel_max=worst, equality_rows_max=float(rv.max()),
+                         complementarity_rows_max=float(kv.max()))
+    return out
+
+
 def check_plumbing_config_callbacks(oracle, lib, device):
     """BASELINE config 1 through the reference-signature callbacks: cartpole with joint friction, x1 = 0, T = 51 (50 steps),
     u_1 = -1.5, the rest 0 (examples/cartpole.jl:15-21,41-46,78) -- f for the rollout, then fx and fu at every knot, one

@@ -275,3 +275,13 @@ def test_lane_cooperation_in_lockstep_rows(oracle, emu_lib, name):
                 P.assert_grad_conditioned(oracle, im, name, X, U, G(cur), G(ref), ((cur[3] & 3) == 3).numpy(), "mapping %d" % ppw)
     finally:
         emu_lib.cdll.od_emu_set_lockstep(0)
+
+
+@pytest.mark.parametrize("name", MECH)
+def test_solutions_zero_the_hand_written_residuals(oracle, emu_lib, name):
+    """oracle/models_np.py (src/models/<model>/model.jl restated by hand) at the solutions the product's kernels return (host build)"""
+    P.check_solutions_against_hand_written_residuals(oracle, emu_lib, "cpu", name, B=256)
+
+
+def test_rocket_solutions_zero_the_hand_written_residuals(oracle, emu_lib):
+    P.check_rocket_solutions_against_hand_written_residuals(oracle, emu_lib, "cpu", B=256)
