@@ -25,8 +25,10 @@ def emu_lib():
     hip_runtime.h (tests/host_emu).  Lets the CPU tier check solver logic + host-side argument
     handling against the oracle.  Never used by the product or by the -m gpu tests."""
     d = os.path.join(ROOT, "tests", "host_emu")
-    subprocess.check_call(["make", "-C", d, "-j", "8"], stdout=subprocess.DEVNULL)
     from optimization_dynamics_amd import _lib
+    if os.environ.get("OD_EMU_LIB"):          # e.g. a sanitizer build of the same sources (tools/asan_tier.sh)
+        return _lib.Library(os.environ["OD_EMU_LIB"])
+    subprocess.check_call(["make", "-C", d, "-j", "8"], stdout=subprocess.DEVNULL)
     return _lib.Library(os.path.join(d, "libod_emu.so"))
 
 
