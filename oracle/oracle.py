@@ -40,7 +40,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        _LIB = C.CDLL(os.environ.get("OD_ORACLE_LIB") or build())       # (OD_ORACLE_LIB: a sanitizer build, tools/asan_tier.sh)
         _LIB.od_oracle_model_name.restype = C.c_char_p
         for i in range(_LIB.od_oracle_num_models_()):          # the generated registry (incl. models added with --add)
             MODEL_IDS[_LIB.od_oracle_model_name(i).decode()] = i

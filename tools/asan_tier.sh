@@ -12,6 +12,9 @@ g++ $FL -c $SRC/od_capi.hip -o $O/od_capi.o &
 g++ $FL -c $E/emu_globals.cpp -o $O/emu_globals.o &
 wait
 g++ -shared -fPIC -fopenmp -pthread -fsanitize=address,undefined -o $O/libod_emu_asan.so $O/*.o
+# the checker too: the CPU oracle (oracle/ip_oracle.c + arbiter.c) under the same sanitizers
+gcc -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fPIC -std=gnu99 -ffp-contract=off -fopenmp -shared -o $O/libod_oracle_asan.so $R/oracle/ip_oracle.c -lquadmath -lm
+export OD_ORACLE_LIB=$O/libod_oracle_asan.so
 cd $R
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=0:detect_odr_violation=0 UBSAN_OPTIONS=print_stacktrace=1 \
   LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" OD_EMU_LIB=$O/libod_emu_asan.so \
