@@ -163,6 +163,9 @@ def test_parameter_stage_argument_checks(emu_lib):
     assert cd.od_ilqr_set_parameter_stage(s, C.byref(q)) == -1
     assert cd.od_ilqr_set_parameter_stage(s, None) == 0                      # removes the stage
     assert cd.od_ilqr_get_trace(s, None, None, None, 0) == 0                 # (no iterations yet: no rows)
+    info0 = _lib.IlqrInfo()
+    assert cd.od_ilqr_get_info(s, C.byref(info0)) == 0 and info0.iterations == 0 and info0.al_iterations == 0    # (state block zeroed at creation)
+    assert cd.od_ilqr_get_trace(s, None, None, None, 5) == 0 and cd.od_ilqr_get_history(s, None, 0) == 0
     assert cd.od_ilqr_get_trace(None, None, None, None, 0) < 0
     assert cd.od_ilqr_destroy(s) == 0
     # a cartpole solver: theta has 4 entries, the hopper's rows act on 8
