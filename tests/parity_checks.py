@@ -1035,11 +1035,11 @@ def check_rocket_sweep(oracle, lib, device, B, seed, dtype=torch.float64, u_max=
     g = lambda a, b: np.abs(a - b).reshape(9, B).max(0) / sc
     dev, orc, cross, expl = g(DP, Ed), g(Go, Eo), g(DP, Go), g(Ed, Eo)
     fin = both & np.isfinite(dev) & np.isfinite(expl) & np.isfinite(cond)
-    assert fin.sum() >= both.sum() - 2
+    assert fin.sum() >= both.sum() - 2, ("projection gradients arbitrated", int(fin.sum()), int(both.sum()))
     eps = 1e-14 if f64 else 2e-7           # (a float factorisation of a system of condition number c is good to ~c x 6e-8)
     bound = np.maximum(EXACT_TOL if f64 else 1e-5, cond * eps)
     assert (dev[fin] <= bound[fin]).all(), ("projection gradient vs binary128 at the device's iterate", float((dev[fin] / bound[fin]).max()), float(dev[fin].max()))
-    assert (orc[fin] <= np.maximum(EXACT_TOL, cond[fin] * 1e-14)).all()
+    assert (orc[fin] <= np.maximum(EXACT_TOL, cond[fin] * 1e-14)).all(), ("oracle's projection gradient vs binary128 at its own iterate", float(orc[fin].max()))
     excess = cross[fin] - 2.0 * expl[fin] - (0.0 if f64 else 1.0) * bound[fin]
     assert excess.max() < GRAD_TOL, ("projection gradient, device vs oracle beyond what their end points explain", float(excess.max()))
     # the projected control

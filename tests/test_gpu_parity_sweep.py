@@ -38,8 +38,8 @@ def test_parity_sweep(oracle, gpu_lib):
             G_dev, G_ora = np.concatenate([DX, DU], 1), np.concatenate([DXo, DUo], 1)
             nan_ora = ~np.isfinite(G_ora).reshape(-1, B).all(0)
             nan_dev = ~np.isfinite(G_dev).reshape(-1, B).all(0)
-            assert not (nan_dev & ok & ~nan_ora).any()
-            assert (nan_ora & ok).sum() <= 2
+            assert not (nan_dev & ok & ~nan_ora).any(), ("non-finite device gradient on a converged knot the oracle differentiates", name, seed, np.nonzero(nan_dev & ok & ~nan_ora)[0][:4].tolist())
+            assert (nan_ora & ok).sum() <= 2, ("singular Jacobians in the oracle", name, seed, int((nan_ora & ok).sum()))
             ok = ok & ~nan_ora
             srel_all = np.abs(D - Do).max(0) / np.maximum(1e-2, np.abs(Do).max(0))
             # A state mismatch is a failure unless the ORACLE ITSELF does not reproduce its answer there: the knot is
