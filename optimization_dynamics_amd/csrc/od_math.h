@@ -149,6 +149,14 @@ OD_HD float od_rsqrt(float x) {
   float y = __builtin_amdgcn_rsqf(x);
   return __builtin_fmaf(__builtin_fmaf(-0.5f * x * y, y, 0.5f), y, y);
 }
+#elif defined(OD_EMULATE_RCP)   // test harness: mimic the device sequence (24-bit seed + 2 Newton steps)
+OD_HD double od_rsqrt(double x) {
+  double y = (double)(float)(1.0 / sqrt(x));
+  const double nhx = -0.5 * x;
+  for (int i = 0; i < 2; ++i) y = std::fma(std::fma(nhx * y, y, 0.5), y, y);
+  return y;
+}
+OD_HD float od_rsqrt(float x) { return 1.0f / sqrtf(x); }
 #else
 OD_HD double od_rsqrt(double x) { return 1.0 / sqrt(x); }
 OD_HD float od_rsqrt(float x) { return 1.0f / sqrtf(x); }

@@ -25,7 +25,7 @@ namespace od {
 // sqrt(x) for the norm in the cone step: x * rsqrt(x) (the library's correctly rounded sqrt expands to ~28 instructions in single
 // precision, ~20 in double; four of them per interior-point iteration); 0 for x = 0
 template <class T> OD_HD T od_sqrt_fast(T x) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(OD_EXACT_RCP)
+#if (defined(__HIP_DEVICE_COMPILE__) && !defined(OD_EXACT_RCP)) || defined(OD_EMULATE_RCP)
   return x > T(0) ? x * od_rsqrt(x) : T(0);
 #else
   return od_sqrt(x);

@@ -398,6 +398,13 @@ OD_HD void ip_iteration(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z
   line_search<M>(o, th, pre, tr, z, D, alpha, r, r_vio, k_vio);
   if (alpha_out) *alpha_out = alpha;
   OD_TRACE_IT("dev it %d alpha %.17g r_vio %.6e k_vio %.6e alpha0 %.6e\n", it + 1, (double)alpha, (double)r_vio, (double)k_vio, (double)alpha0_);
+#ifdef OD_TRACE
+  if (od_trace_flag > 1) {          // level 2: the iterate as well
+    std::printf("dev z%d", it + 1);
+    for (int k = 0; k < M::NZ; ++k) std::printf(" %.17g", (double)z[k]);
+    std::printf("\n");
+  }
+#endif
 }
 
 // sinks that want every row of dz (not only the solution block ZQ) declare `static constexpr bool ALL_ROWS = true`

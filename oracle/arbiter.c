@@ -180,6 +180,7 @@ static q128 q_soc_step_one(int n, const q128* lam, const q128* dlt, q128 tau) {
   if (nv - rs > 0) { q128 cnd = tau / (nv - rs); if (cnd < a) a = cnd; }
   return a;
 }
+extern int od_oracle_trace;   /* ip_oracle.c */
 static q128 q_step_length(const od_oracle_model* m, const q128* z, const q128* D, q128 tau_ort, q128 tau_soc) {
   q128 a = 1, lam[8], dl[8];
   for (int s = 0; s < 2; ++s) {
@@ -268,6 +269,11 @@ int od_arbiter_soc_projection(double u_max, const double* u, int exact_acceptanc
     for (int k = 0; k < nz; ++k) r[k] = rcand[k];
     r_vio = r_c;
     k_vio = k_c;
+    if (od_oracle_trace) {
+      printf("arb it %d alpha %.17g r_vio %.6e k_vio %.6e trial %d z", iters, (double)alpha, (double)r_vio, (double)k_vio, tr);
+      for (int k = 0; k < nz; ++k) printf(" %.17g", (double)z[k]);
+      printf("\n");
+    }
   }
   for (int i = 0; i < nz; ++i) z_out[i] = (double)z[i];
   if (iters_out) *iters_out = iters;

@@ -266,7 +266,11 @@ static int ip_solve_impl(int model_id, const od_oracle_opts* o, double kappa_tol
     memcpy(z, zc, sizeof(double) * nz);
     r_vio = r_c;
     k_vio = k_c;
-    if (od_oracle_trace) printf("ora it %d alpha %.17g r_vio %.6e k_vio %.6e\n", iters, alpha, r_vio, k_vio);
+    if (od_oracle_trace) {
+      printf("ora it %d alpha %.17g r_vio %.6e k_vio %.6e z", iters, alpha, r_vio, k_vio);
+      for (int k = 0; k < nz; ++k) printf(" %.17g", z[k]);
+      printf("\n");
+    }
   }
   if (iters_out) *iters_out = iters;
   int status = (r_vio < o->r_tol && k_vio < kappa_tol) ? 1 : 0;   /* NaN -> 0 */
