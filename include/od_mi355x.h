@@ -62,6 +62,11 @@ typedef struct {
   double eps_min, kappa_reg, gamma_reg, undercut;
 } od_options;
 
+/* ABI version of this header; od_version() returns the library's.  Bumped whenever a struct passed by pointer changes size or a default
+ * changes behaviour (100 -> 101: od_ilqr_options gained rho_max and proj_stall_exit, handles start with the projection's stall exit off,
+ * the od_comm_* entry points; a single-precision handle solves the thrust-cone projection in double under od_set_mixed_precision).
+ * Bindings compare the two at load (optimization_dynamics_amd/_lib.py, julia/OptimizationDynamicsMI355X.jl). */
+#define OD_ABI_VERSION 101
 int od_version(void);
 const char* od_last_error(void);
 
@@ -168,6 +173,30 @@ int od_rollout(od_handle h, long B, int T, const void* x1, const void* U, void* 
  * a multi-GPU gather of the linearisation should ship. */
 int od_rollout_compact(od_handle h, long B, int T, const void* x1, const void* U, void* X, void* dq3,
                        int* status, int* iters);
+
+/* ---- multi-GPU: one host process per GPU, rollouts sharded, no collective on the data path.  The one exchange the
+ * path can have -- an all-gather of the per-knot linearisation for an outer loop whose backward pass runs on every rank (or on the host),
+ * the consumer being IterativeLQR's Riccati pass (examples/acrobot.jl:97-113) -- sits behind the boundary too, over RCCL on the handle's
+ * stream, so that a Julia process per GPU needs nothing but `ccall`.  The reference has no distributed code: these
+ * entry points replace nothing, they are what its single process turns into on eight devices.
+ *
+ * od_comm_unique_id: rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks out of band (a file, a socket,
+ * Julia's Distributed).  od_comm_create: every rank, same id, its rank and the world size -- a collective call (ncclCommInitRank) on
+ * the handle's device; the communicator belongs to that device.  od_comm_info: size and rank as the communicator reports them
+ * (ncclCommCount / ncclCommUserRank) and its device.  OD_ERR_UNSUPPORTED where librccl cannot be loaded. */
+#define OD_COMM_ID_BYTES 128
+typedef struct od_comm_s* od_comm;
+int od_comm_unique_id(void* id /* OD_COMM_ID_BYTES, host */);
+int od_comm_create(od_handle h, const void* id, int rank, int world, od_comm* out);
+int od_comm_info(od_comm c, int* world, int* rank, int* device);
+int od_comm_destroy(od_comm c);
+/* all-gather of od_rollout_compact's outputs of B trajectories x T steps per rank (every rank the same B and T: pad the last shard):
+ * X (2nq per slot, (T+1)*B slots) -> X_all, dq3 (nq x (2nq+nu) per knot, T*B knots) -> dq3_all; either pair may be NULL.  Block r of an
+ * output is rank r's array as it stands (its layout, its B): X_all = world blocks of 2nq*(T+1)*B doubles, dq3_all = world blocks of
+ * nq*(2nq+nu)*T*B.  Device pointers; asynchronous on the handle's stream, after the rollout that was queued there. */
+int od_allgather_compact(od_handle h, od_comm c, long B, int T, const void* X, const void* dq3, void* X_all, void* dq3_all);
+/* the same for any device buffer of `bytes` bytes per rank (recv: world * bytes) -- e.g. the gains of a backward pass that ran on one rank */
+int od_comm_allgather(od_handle h, od_comm c, const void* send, void* recv, size_t bytes);
 
 /* ---- next row of the scope table: the iLQR iteration around the path -----------------
  * Forward pass / Armijo line search of IterativeLQR (iLQR.solve!, examples/acrobot.jl:113): closed-loop

@@ -1329,6 +1329,13 @@ int run_step(od_handle_s* h, const char* fn, long B, const void* x, const void* 
 
 }  // namespace
 
+// the thrust-cone projection's options as a double-precision handle runs it (single-precision handles under od_set_mixed_precision)
+static Opts<double> proj_opts64() {
+  od_options po;
+  defaults_of(vt_rocket_projection(), &po);
+  return to_opts<double>(po);
+}
+
 template <class T> static int rocket_impl(od_handle h, long B, int project, const void* x, const void* u, void* y,
                                           void* dx, void* du, void* uproj, int* status) {
   const int L = h->layout;
@@ -1343,6 +1350,7 @@ template <class T> static int rocket_impl(od_handle h, long B, int project, cons
     po.r_tol = std::fmax(po.r_tol, (double)h->opts.r_tol);
   }
   a.opts_proj = to_opts<T>(po);
+  a.opts_proj64 = proj_opts64();
   a.project = project;
   a.want_grad = (dx || du) ? 1 : 0;
   a.x = mkcview<T>(x, 12, B, L);
@@ -1371,6 +1379,7 @@ template <class T> static RocketArgs<T> rocket_args(od_handle h, long B, int pro
   defaults_of(vt_rocket_projection(), &po);
   if (h->dtype == OD_F32) po.r_tol = std::fmax(po.r_tol, (double)h->opts.r_tol);   // tolerances reachable in fp32
   a.opts_proj = to_opts<T>(po);
+  a.opts_proj64 = proj_opts64();
   a.project = project;
   a.want_grad = want_grad;
   a.x.p = nullptr; a.u.p = nullptr; a.y.p = nullptr; a.dx.p = nullptr; a.du.p = nullptr; a.uproj.p = nullptr; a.status.p = nullptr;
@@ -1428,7 +1437,7 @@ template <class T> static int rocket_rollout_impl(od_handle h, long B, int Tn, i
 
 extern "C" {
 
-int od_version(void) { return 100; }
+int od_version(void) { return OD_ABI_VERSION; }
 const char* od_last_error(void) { return g_err.c_str(); }
 
 int od_model_dims(int model, int* nq, int* nu, int* nz, int* ntheta, int* nfric) {
@@ -2239,3 +2248,5 @@ int od_bundle_grad_host(od_handle h, int N, const double* x, const double* u, co
 
 #include <vector>
 #include "od_ilqr_solver.inc"
+
+#include "od_comm.inc"

@@ -84,22 +84,39 @@ struct Model_rocket_projection_direct : Model_rocket_projection {
     return p;
   }
   // largest alpha in (0, 1] keeping z - alpha D inside the cones (od_solver.h::step_length for this model)
-  template <class T> OD_HD static T direct_step_length(const StepPre<T>& p, const T* z, const T* D, T tau_ort, T tau_soc) {
+  // blk (optional): the orthant variable whose ratio test set the step (-1: a cone, or the full step)
+  template <class T> OD_HD static T direct_step_length(const StepPre<T>& p, const T* z, const T* D, T tau_ort, T tau_soc, int* blk = nullptr) {
     // orthant pairs (s, w) and (u3, p): ORT1 = {4, 2}, ORT2 = {5, 3}; min of the ratio tests kept as a fraction
     T num = T(1), den = T(1);
+    int kb = -1;
     constexpr int K[4] = {4, 5, 2, 3};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const T n1 = tau_ort * z[K[i]];
-      if (D[K[i]] > T(0) && n1 * den < num * D[K[i]]) { num = n1; den = D[K[i]]; }
+      if (D[K[i]] > T(0) && n1 * den < num * D[K[i]]) { num = n1; den = D[K[i]]; kb = K[i]; }
     }
-    T a = num * od_rcp(den);
+    const T ao = num * od_rcp(den);
+    T a = ao;
     a = od_min(a, cone_step<T>(p.u, D[2], D[0], D[1], tau_soc));
     a = od_min(a, cone_step<T>(p.v, D[9], D[7], D[8], tau_soc));
+    if (blk) *blk = a < ao ? -1 : kb;
     return a;
   }
-  // u0 u1 u2 | s w | a0 a1 1/a2 | inverse of the 3 x 3 block, row-major (9)
-  template <class T> struct Fact { T v[17]; };
+  // A full step to the boundary of an orthant (eps_min = 0: tau = 1, src/models/rocket/dynamics.jl:81) ends, in exact arithmetic, with
+  // the blocking variable EXACTLY zero: z_k - (z_k / D_k) D_k.  In floating point it ends on the rounding residual of the division (a
+  // fused multiply-add returns exactly that residual: +-1e-17, either sign), and the algorithm is discontinuous there -- the next
+  // affine direction of a variable at zero is zero times something, the sign of its noise decides between "blocked at step length
+  // 0" (sigma = 1) and "not blocking" (sigma ~ 0), and the iterates part at the 1e-3 level (tools/proj_paths_host.py).  The line search
+  // sets the blocking variable of an accepted full step to its exact value (od_solver.h::ls_trial), and `solve` below returns the
+  // exact component of a variable that sits at zero, so that the device follows the exact-arithmetic path through such a landing.
+  static constexpr bool SNAP_BLOCKING = true;
+  // rows 0-4 of the residual (src/models/rocket/codegen.jl:53-57) are linear in z: the line search accepts as exact arithmetic does
+  // (od_solver.h::ls_trial)
+  static constexpr bool LINEAR_EQ_ROWS = true;
+  static constexpr int NSNAP = 4;
+  static constexpr int SNAP[4] = {4, 5, 2, 3};
+  // u0 u1 u2 | s w | a0 a1 1/a2 | inverse of the 3 x 3 block, row-major (9) | p
+  template <class T> struct Fact { T v[18]; };
 
   // z: the iterate with its orthant variables clamped (eval_factor); the Jacobian does not depend on theta
   template <bool PIV = true, class T, class F> OD_HD static bool direct_factor(const T* z, F& f) {
@@ -118,6 +135,7 @@ struct Model_rocket_projection_direct : Model_rocket_projection {
     f.v[8] = -u2 * G * id;  f.v[9] = s * G * id;   f.v[10] = -s * u2 * id;
     f.v[11] = -pg * id;     f.v[12] = -w * G * id; f.v[13] = w * u2 * id;
     f.v[14] = p * G * id;   f.v[15] = wg * id;     f.v[16] = s * p * id;
+    f.v[17] = p;
     return oka && okd;
   }
 
@@ -136,9 +154,22 @@ struct Model_rocket_projection_direct : Model_rocket_projection {
     const T q = dy + dp;
     const T du0 = (c8 - a0 * du2 + u0 * q) * ia2;
     const T du1 = (c9 - a1 * du2 + u1 * q) * ia2;
-    x[0] = du0; x[1] = du1; x[2] = du2; x[3] = dp;
-    x[4] = -du2 - b3;
-    x[5] = -dy - b4;
+    T ds = -du2 - b3, dw = -dy - b4;
+    // a variable of an orthant pair that sits EXACTLY at zero (the landing of a full step, SNAP_BLOCKING): its row of the system,
+    // s Dw + w Ds = b5 or p Du2 + u2 Dp = b6, has one entry left and gives the component exactly -- zero for the affine direction,
+    // -kappa / partner for the corrector -- where the elimination order above returns it as a difference of O(1) terms, i.e. as
+    // rounding noise of either sign (a pivoted LU takes that row as it stands: same system, same solution, no noise)
+    const T pp = f.v[17];
+    T du2o = du2, dpo = dp;
+    if (od_any_lane(s == T(0) || w == T(0) || u2 == T(0) || pp == T(0))) {
+      if (w == T(0) && s != T(0)) dw = b[5] * od_rcp(s);
+      if (s == T(0) && w != T(0)) ds = b[5] * od_rcp(w);
+      if (pp == T(0) && u2 != T(0)) dpo = b6 * od_rcp(u2);
+      if (u2 == T(0) && pp != T(0)) du2o = b6 * od_rcp(pp);
+    }
+    x[0] = du0; x[1] = du1; x[2] = du2o; x[3] = dpo;
+    x[4] = ds;
+    x[5] = dw;
     x[6] = dy;
     x[7] = du0 - b0; x[8] = du1 - b1; x[9] = du2 - q - b2;
   }

@@ -299,18 +299,37 @@ template <class M, class = void> struct model_no_lane_copies : std::false_type {
 template <class M> struct model_no_lane_copies<M, std::void_t<decltype(M::DIRECT_STEP)>> : std::true_type {};   // (the rocket kernels map one problem to one lane)
 template <class M> constexpr bool parallel_line_search() { return M::NZ <= 20 && !model_no_lane_copies<M>::value; }
 
+// models whose full step to an orthant boundary is completed exactly (od_rocket_proj_direct.h) declare `static constexpr bool SNAP_BLOCKING = true`
+template <class M, class = void> struct model_snap_blocking : std::false_type {};
+template <class M> struct model_snap_blocking<M, std::void_t<decltype(M::SNAP_BLOCKING)>> : std::bool_constant<M::SNAP_BLOCKING> {};
+
+// models whose equality rows are linear in z declare `static constexpr bool LINEAR_EQ_ROWS = true`
+template <class M, class = void> struct model_linear_eq : std::false_type {};
+template <class M> struct model_linear_eq<M, std::void_t<decltype(M::LINEAR_EQ_ROWS)>> : std::bool_constant<M::LINEAR_EQ_ROWS> {};
+
+// snap: index of the orthant variable that blocks the step at tau = 1 (the trial at that very step length only), or -1
 template <class M, class T>
-OD_HD bool ls_trial(const T* th, const T* pre, T* tr, const T* z, const T* D, T alpha, T r_vio, T k_vio, T* zc, T* r, T& r_c, T& k_c) {
+OD_HD bool ls_trial(const T* th, const T* pre, T* tr, const T* z, const T* D, T alpha, T r_vio, T k_vio, T* zc, T* r, T& r_c, T& k_c, int snap = -1) {
 #pragma unroll
   for (int i = 0; i < M::NZ; ++i) zc[i] = z[i] - alpha * D[i];
+  if constexpr (model_snap_blocking<M>::value) {
+#pragma unroll
+    for (int i = 0; i < M::NSNAP; ++i) zc[M::SNAP[i]] = (M::SNAP[i] == snap) ? T(0) : zc[M::SNAP[i]];
+  }
   M::eval_r(zc, th, pre, tr, r);
   r_c = viol_eq<M>(r);
   k_c = viol_bil<M>(r);
+  // Equality rows that are LINEAR in z (M::LINEAR_EQ_ROWS): r_eq(z - alpha D) = (1 - alpha) r_eq(z) for the Newton direction D, so the
+  // first disjunct holds in exact arithmetic for every alpha in [0, 1] and the first trial is the accepted one.  Evaluated in floating
+  // point, from the first full step on both sides of `r_c <= r_vio` are the rounding noise of a residual that is exactly zero, and the
+  // test -- whenever the complementarity violation rises, which it does next to the apex of the cone -- is a coin toss that no two
+  // implementations (this one, the oracle, the reference on another BLAS) throw alike.  The test is evaluated as exact arithmetic would.
+  if constexpr (model_linear_eq<M>::value) return true;
   return r_c <= r_vio || k_c <= k_vio;
 }
 
 template <class M, class T>
-OD_HD void line_search(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z, const T* D, T& alpha, T* r, T& r_vio, T& k_vio) {
+OD_HD void line_search(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z, const T* D, T& alpha, T* r, T& r_vio, T& k_vio, int snap = -1) {
   T zc[M::NZ];
 #pragma unroll
   for (int i = 0; i < M::NZ; ++i) zc[i] = z[i];        // (max_ls < 1 is rejected at the API; never copy garbage back)
@@ -320,7 +339,7 @@ OD_HD void line_search(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z,
   bool done = false;
   int ls = 0;
   for (; ls < nseq; ++ls) {
-    if (ls_trial<M>(th, pre, tr, z, D, alpha, r_vio, k_vio, zc, r, r_c, k_c)) { done = true; break; }
+    if (ls_trial<M>(th, pre, tr, z, D, alpha, r_vio, k_vio, zc, r, r_c, k_c, ls == 0 ? snap : -1)) { done = true; break; }
     if (ls + 1 < o.max_ls) alpha *= T(0.5);            // alpha stays at the last trial's value if all of them fail
   }
   if constexpr (parallel_line_search<M>()) {
@@ -367,8 +386,10 @@ OD_HD void ip_iteration(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z
   if (!eval_factor<M, PIV>(z, th, pre, tr, reg, f)) status &= ~OD_ST_FACTOR_OK;
   T D[M::NZ];
   M::template solve<PIV>(f, r, D);                     // affine (predictor) direction
+  int blk = -1;                                         // (SNAP_BLOCKING models: the orthant variable that sets the last step length computed)
   auto steplen = [&](const T* D_, T tau_ort, T tau_soc, const auto& pre_) {
-    if constexpr (model_direct_step<M>::value) return M::template direct_step_length<T>(pre_, z, D_, tau_ort, tau_soc);
+    if constexpr (model_snap_blocking<M>::value) return M::template direct_step_length<T>(pre_, z, D_, tau_ort, tau_soc, &blk);
+    else if constexpr (model_direct_step<M>::value) return M::template direct_step_length<T>(pre_, z, D_, tau_ort, tau_soc);
     else return step_length<M>(z, D_, tau_ort, tau_soc, o.coop);
   };
   auto make_pre = [&]() {
@@ -395,7 +416,12 @@ OD_HD void ip_iteration(const Opts<T>& o, const T* th, const T* pre, T* tr, T* z
 #ifdef OD_TRACE
   const T alpha0_ = alpha;
 #endif
-  line_search<M>(o, th, pre, tr, z, D, alpha, r, r_vio, k_vio);
+  if constexpr (model_snap_blocking<M>::value) {
+    if (!(tau == T(1))) blk = -1;                      // (only a step that goes ALL the way to the boundary ends on it)
+    line_search<M>(o, th, pre, tr, z, D, alpha, r, r_vio, k_vio, blk);
+  } else {
+    line_search<M>(o, th, pre, tr, z, D, alpha, r, r_vio, k_vio);
+  }
   if (alpha_out) *alpha_out = alpha;
   OD_TRACE_IT("dev it %d alpha %.17g r_vio %.6e k_vio %.6e alpha0 %.6e\n", it + 1, (double)alpha, (double)r_vio, (double)k_vio, (double)alpha0_);
 #ifdef OD_TRACE

@@ -477,8 +477,9 @@ template <class T> struct RocketArgs {
   const int* live;    // per trajectory: knot b belongs to trajectory b % live_mod and is computed only if live[b % live_mod] != 0
   long live_mod;
   int proj_stall_exit; // 1: a projection solve that has stalled at the boundary of the cone is abandoned (od_solver.h::model_stall)
-  int polish64;        // single-precision handles: 1 = the dynamics solution refined with the residual in double (rocket_refine64) and the implicit gradient from a double factorisation there (rocket_grad64)
+  int polish64;        // single-precision handles: 1 = the dynamics solution refined with the residual in double (rocket_refine64) and the implicit gradient from a double factorisation there (rocket_grad64); the thrust-cone projection solved in double (soc_project_solve)
   double h64;          // the time step in double (h is rounded to T)
+  Opts<double> opts_proj64;   // the projection's options as a double-precision handle has them (soc_project_solve)
 };
 
 // d(projected u)/du: 3 x 3 col-major kept in registers (column index is dynamic -> selects)
@@ -575,6 +576,54 @@ template <class MD, class F32> OD_HD void rocket_refine64(const float* x, const 
   for (int i = 0; i < MD::NZ; ++i) y[i] = (float)(z[i] - (double)D[i]);
 }
 
+// The thrust-cone projection of a single-precision handle under od_set_mixed_precision (the default): the whole solve in double, on the
+// float inputs, rounded to float on the way out -- the projected control and its gradient are the double-precision handle's to float
+// resolution (6e-8).  An interior-point solve has no "solution" to polish: it returns the first iterate below kappa_tol, a point of the
+// path, and the path is ill-conditioned in its own rounding -- every iteration multiplies the duality measure by (1 - alpha) with
+// alpha = 0.97-0.999, so a relative error e of alpha becomes e / (1 - alpha) of the measure, and next to the apex of the cone the
+// iterate moves like its square root.  Measured on the host build (tools/proj_paths_host.py, profiles/r6_projection_paths_host.json): a
+// float solve agrees with the double one to 1e-6 on 65 % of apex-heavy controls (2e-3 on all); a variant that ran the float iterations
+// down to k_vio < 1 (or 100: the first three) and the remaining ones in double reached 90 % and was dropped -- three float iterations at
+// the start are enough to lose it.  Round 5's float projection remains under od_set_mixed_precision(h, 0).
+template <class S> struct CastSinkFull64 {
+  static constexpr bool DEFER_GRAD = false;
+  static constexpr bool FULL_STATE = true;
+  S& s;
+  OD_HD void defer(const double*, double) {}
+  OD_HD void grad(int i, int c, double v) { s.grad(i, c, (float)v); }
+};
+template <class T> struct FullStateNoGradSink {
+  static constexpr bool DEFER_GRAD = true;     // (never asked for a gradient: no gradient code in the kernel)
+  static constexpr bool FULL_STATE = true;
+  OD_HD void grad(int, int, T) {}
+  OD_HD void defer(const T*, T) {}
+};
+// zp: in = the initial guess soc_projection prescribes (MP::ZI_VAL), out = the whole solution vector; GRAD = false: kernels that never take the projection's gradient
+template <class MP, bool GRAD, class T, class Sink>
+OD_HD int soc_project_solve(const RocketArgs<T>& a, const T* thp, T* zp, bool want_grad, Sink& sink, int* itp) {
+  if constexpr (sizeof(T) == 4) {
+    if (a.polish64) {
+      double z[MP::NZ], th[MP::NTH];
+#pragma unroll
+      for (int i = 0; i < MP::NZ; ++i) z[i] = MP::ZI_VAL[i];      // (the initial point of soc_projection in double: 0.1 is not a float)
+#pragma unroll
+      for (int i = 0; i < MP::NTH; ++i) th[i] = (double)thp[i];
+      int st;
+      if constexpr (GRAD) {
+        CastSinkFull64<Sink> cs{sink};
+        st = ip_step_grad<MP>(a.opts_proj64, th, z, true, want_grad, cs, itp, a.proj_stall_exit != 0);
+      } else {
+        FullStateNoGradSink<double> ns;
+        st = ip_step_grad<MP>(a.opts_proj64, th, z, true, false, ns, itp, a.proj_stall_exit != 0);
+      }
+#pragma unroll
+      for (int i = 0; i < MP::NZ; ++i) zp[i] = (float)z[i];
+      return st;
+    }
+  }
+  return ip_step_grad<MP>(a.opts_proj, thp, zp, true, want_grad, sink, itp, a.proj_stall_exit != 0);
+}
+
 // one rocket knot: (x, u) in registers -> y in registers; per-knot outputs (dx, du, uproj, status) at index b
 // GRADS = false (the rollout kernels): state only -- no gradient code in the kernel at all (it would never run there, but its
 // arrays would still shape the register allocation of the time recursion)
@@ -590,7 +639,7 @@ template <class MD, class MP, class T> OD_HD void rocket_knot_state(const Rocket
     for (int i = 0; i < MP::NZ; ++i) zp[i] = T(MP::ZI_VAL[i]);
     thp[0] = u[0]; thp[1] = u[1]; thp[2] = u[2]; thp[3] = a.u_max;
     int itp[2];
-    const int sp_ = ip_step_grad<MP>(a.opts_proj, thp, zp, true, false, ns, itp, a.proj_stall_exit != 0);
+    const int sp_ = soc_project_solve<MP, false>(a, thp, zp, false, ns, itp);
 #ifdef OD_EXPERIMENT_ITERS_IN_STATUS
     itp_[0] = itp[1];
 #endif
@@ -631,7 +680,7 @@ OD_HD void rocket_knot(const RocketArgs<T>& a, long b, const T* x, T* u, T* y) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) dproj[i] = T(0);
     int itp[2];
-    const int sp_ = ip_step_grad<MP>(a.opts_proj, thp, zp, true, a.want_grad != 0, ps, itp, a.proj_stall_exit != 0);
+    const int sp_ = soc_project_solve<MP, true>(a, thp, zp, a.want_grad != 0, ps, itp);
     st |= (sp_ & 3) << 4;
     u[0] = zp[0]; u[1] = zp[1]; u[2] = zp[2];
     if (a.uproj.ok()) { a.uproj.at(0, b) = u[0]; a.uproj.at(1, b) = u[1]; a.uproj.at(2, b) = u[2]; }
@@ -707,7 +756,7 @@ template <class MP, class T> OD_HD void unit_soc_project(const SocProjectArgs<T>
   for (int i = 0; i < 9; ++i) dproj[i] = T(0);
   ProjSink<T> ps{dproj};
   int itp[2];
-  const int sp_ = ip_step_grad<MP>(a.opts_proj, thp, zp, true, a.want_grad != 0, ps, itp, a.proj_stall_exit != 0);
+  const int sp_ = soc_project_solve<MP, true>(a, thp, zp, a.want_grad != 0, ps, itp);
   if (a.uproj.ok()) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) a.uproj.at(i, b) = zp[i];

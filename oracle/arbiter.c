@@ -181,12 +181,15 @@ static q128 q_soc_step_one(int n, const q128* lam, const q128* dlt, q128 tau) {
   return a;
 }
 extern int od_oracle_trace;   /* ip_oracle.c */
-static q128 q_step_length(const od_oracle_model* m, const q128* z, const q128* D, q128 tau_ort, q128 tau_soc) {
+/* blk (optional): the orthant variable whose ratio test set the step length, -1 if a cone did or the step is the full one */
+static q128 q_step_length_blk(const od_oracle_model* m, const q128* z, const q128* D, q128 tau_ort, q128 tau_soc, int* blk) {
   q128 a = 1, lam[8], dl[8];
+  int kb = -1;
   for (int s = 0; s < 2; ++s) {
     const int* idx = s == 0 ? m->ort1 : m->ort2;
-    for (int i = 0; i < m->nort; ++i) { int k = idx[i]; if (D[k] > 0) { q128 c = tau_ort * z[k] / D[k]; if (c < a) a = c; } }
+    for (int i = 0; i < m->nort; ++i) { int k = idx[i]; if (D[k] > 0) { q128 c = tau_ort * z[k] / D[k]; if (c < a) { a = c; kb = k; } } }
   }
+  const q128 ao = a;
   for (int c = 0; c < m->nsoc; ++c) {
     int o = m->socoff[c], n = m->socoff[c + 1] - o;
     for (int s = 0; s < 2; ++s) {
@@ -196,7 +199,22 @@ static q128 q_step_length(const od_oracle_model* m, const q128* z, const q128* D
       if (cnd < a) a = cnd;
     }
   }
+  if (blk) *blk = a < ao ? -1 : kb;
   return a;
+}
+static q128 q_step_length(const od_oracle_model* m, const q128* z, const q128* D, q128 tau_ort, q128 tau_soc) {
+  return q_step_length_blk(m, z, D, tau_ort, tau_soc, NULL);
+}
+
+/* An orthant variable that sits exactly at zero (the landing of a full step, below): its complementarity row z_a D_b + z_b D_a = rhs has
+ * one entry left and gives D_a = rhs / z_b exactly -- zero for the affine direction.  The binary128 LU returns it with 1e-34 of noise of
+ * either sign, and `D[k] > 0` of the ratio test would read that sign (blocked at step length 0, sigma = 1, or not blocking at all). */
+static void q_exact_boundary_rows(const od_oracle_model* m, const q128* z, const q128* rhs, q128* x) {
+  for (int i = 0; i < m->nort; ++i) {
+    int a = m->ort1[i], b = m->ort2[i], row = m->ortr[i];
+    if (z[a] == 0 && z[b] != 0) x[a] = rhs[row] / z[b];
+    if (z[b] == 0 && z[a] != 0) x[b] = rhs[row] / z[a];
+  }
 }
 
 /* u (3), u_max -> z (10, rounded to double), iterations, trials[it] = index of the accepted line-search trial of iteration
@@ -220,6 +238,7 @@ int od_arbiter_soc_projection(double u_max, const double* u, int exact_acceptanc
     if (!q_lu_factor(nz, rz, piv)) break;
     for (int i = 0; i < nz; ++i) Da[i] = r[i];
     q_lu_solve(nz, rz, piv, Da);
+    q_exact_boundary_rows(m, z, r, Da);
     q128 aaff = q_step_length(m, z, Da, 1, 1);
     q128 s = 0, sa = 0;
     for (int i = 0; i < m->nort; ++i) { int a = m->ort1[i], b = m->ort2[i]; s += z[a] * z[b]; sa += (z[a] - aaff * Da[a]) * (z[b] - aaff * Da[b]); }
@@ -241,10 +260,13 @@ int od_arbiter_soc_projection(double u_max, const double* u, int exact_acceptanc
     }
     for (int i = 0; i < nz; ++i) D[i] = r[i];
     q_lu_solve(nz, rz, piv, D);
+    q_exact_boundary_rows(m, z, r, D);
     q128 vio = r_vio > k_vio ? r_vio : k_vio, eps = vio * vio;
     if ((q128)o->eps_min < eps) eps = o->eps_min;
     q128 tau = 1 - eps;
-    q128 alpha = q_step_length(m, z, D, tau, tau < 0.99Q ? tau : 0.99Q);
+    int blk = -1;
+    q128 alpha = q_step_length_blk(m, z, D, tau, tau < 0.99Q ? tau : 0.99Q, &blk);
+    if (!exact_acceptance || tau != 1) blk = -1;
     q128 r0[10];
     projq_r(z, th, 0, r0);
     q128 r_c = 0, k_c = 0;
@@ -252,6 +274,10 @@ int od_arbiter_soc_projection(double u_max, const double* u, int exact_acceptanc
     for (int i = 0; i < o->max_ls; ++i) {
       tr = i;
       for (int k = 0; k < nz; ++k) zc[k] = z[k] - alpha * D[k];
+      /* exact arithmetic: a full step (tau = 1) to the boundary of an orthant leaves the blocking variable exactly at zero,
+       * z_k - (z_k / D_k) D_k; binary128 leaves the rounding residual of the division (1e-34, either sign), and the algorithm is
+       * discontinuous there (the sign of the next affine direction of that variable) -- completed exactly */
+      if (i == 0 && blk >= 0) zc[blk] = 0;
       projq_r(zc, th, 0, rcand);
       r_c = q_viol(m->equr, m->neq, rcand);
       k_c = q_viol(m->bil, m->nbil, rcand);

@@ -22,6 +22,16 @@
 int od_oracle_trace = 0;   /* tests can switch on a per-iteration trace */
 void od_oracle_set_trace(int v) { od_oracle_trace = v; }
 
+/* od_oracle_set_exact_boundary(1): the thrust-cone projection's loop (eps_min = 0: full steps to the boundary of an orthant, tau = 1)
+ * with the three places completed as exact arithmetic has them, where the literal double-precision transcription (the default, 0) reads
+ * rounding noise: (a) the blocking variable of an accepted full step is exactly zero; (b) the direction component of a variable that sits
+ * at zero comes from its own complementarity row (one entry left: exact); (c) the line search's `r_c <= r_vio` on the LINEAR equality rows
+ * holds for every step length, so the first trial is accepted.  This is the algorithm oracle/arbiter.c::od_arbiter_soc_projection runs in
+ * binary128 with exact acceptance, in double and with the dense pivoted LU: a second implementation of the exact-arithmetic path, to which
+ * the device's closed-form solve is compared at 1e-6 (tests/parity_checks.py::check_rocket_sweep).  The default stays the literal loop. */
+int od_oracle_exact_boundary = 0;
+void od_oracle_set_exact_boundary(int v) { od_oracle_exact_boundary = v; }
+
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
 #endif
@@ -163,6 +173,27 @@ static double step_length(const od_oracle_model* m, const double* z, const doubl
   double b = soc_step_length(m, z, D, tau_soc);
   return a < b ? a : b;
 }
+/* the orthant variable whose ratio test sets step_length(), -1 if a cone does or the step is the full one */
+static int blocking_variable(const od_oracle_model* m, const double* z, const double* D, double tau_ort, double tau_soc) {
+  double a = 1.0;
+  int kb = -1;
+  for (int s = 0; s < 2; ++s) {
+    const int* idx = s == 0 ? m->ort1 : m->ort2;
+    for (int i = 0; i < m->nort; ++i) {
+      int k = idx[i];
+      if (D[k] > 0.0) { double c = tau_ort * z[k] / D[k]; if (c < a) { a = c; kb = k; } }
+    }
+  }
+  return soc_step_length(m, z, D, tau_soc) < a ? -1 : kb;
+}
+/* (b) of od_oracle_set_exact_boundary: z_a D_b + z_b D_a = rhs with z_a = 0 exactly gives D_a = rhs / z_b */
+static void exact_boundary_rows(const od_oracle_model* m, const double* z, const double* rhs, double* x) {
+  for (int i = 0; i < m->nort; ++i) {
+    int a = m->ort1[i], b = m->ort2[i], row = m->ortr[i];
+    if (z[a] == 0.0 && z[b] != 0.0) x[a] = rhs[row] / z[b];
+    if (z[b] == 0.0 && z[a] != 0.0) x[b] = rhs[row] / z[a];
+  }
+}
 
 /* CVXOPT sec. 5.1.3: mu = <primal, dual> / (number of cones), sigma = clamp(mu_aff/mu,0,1)^3 */
 static void centering(const od_oracle_model* m, const double* z, const double* Da, double aaff, double* mu, double* sigma) {
@@ -233,8 +264,10 @@ static int ip_solve_impl(int model_id, const od_oracle_opts* o, double kappa_tol
     reg_val = (k_vio < o->kappa_reg) ? k_vio * o->gamma_reg : 0.0;
     rz_reg(m, rz, z, th, reg_val);
     lu_factor(nz, rz, piv);
+    const int exact = od_oracle_exact_boundary && model_id == 6 /* ROCKET_PROJ: linear equality rows, eps_min = 0 */;
     memcpy(Da, r, sizeof(double) * nz);
     lu_solve(nz, rz, piv, Da);                       /* affine direction */
+    if (exact) exact_boundary_rows(m, z, r, Da);
     if (ncone > 0) {
       double aaff = step_length(m, z, Da, 1.0, 1.0);
       double mu, sigma;
@@ -246,6 +279,7 @@ static int ip_solve_impl(int model_id, const od_oracle_opts* o, double kappa_tol
       correction_term(m, r, Da);
       memcpy(D, r, sizeof(double) * nz);
       lu_solve(nz, rz, piv, D);                      /* corrector direction, factors reused */
+      if (exact) exact_boundary_rows(m, z, r, D);
     } else {
       memcpy(D, Da, sizeof(double) * nz);            /* no cones: plain Newton */
     }
@@ -254,13 +288,15 @@ static int ip_solve_impl(int model_id, const od_oracle_opts* o, double kappa_tol
     if (o->eps_min < eps) eps = o->eps_min;
     double tau = 1.0 - eps;                          /* progress!: tau = 1 - min(eps_min, vio^2) */
     double alpha = step_length(m, z, D, tau, tau < 0.99 ? tau : 0.99);
+    const int blk = (exact && tau == 1.0) ? blocking_variable(m, z, D, tau, tau < 0.99 ? tau : 0.99) : -1;
     double r_c = 0.0, k_c = 0.0;
     for (int i = 0; i < o->max_ls; ++i) {
       for (int k = 0; k < nz; ++k) zc[k] = z[k] - alpha * D[k];
+      if (i == 0 && blk >= 0) zc[blk] = 0.0;
       m->r(zc, th, 0.0, r);
       r_c = residual_violation(m, r);
       k_c = bilinear_violation(m, r);
-      if (r_c <= r_vio || k_c <= k_vio) break;
+      if (exact || r_c <= r_vio || k_c <= k_vio) break;
       alpha *= 0.5;
     }
     memcpy(z, zc, sizeof(double) * nz);

@@ -342,8 +342,16 @@ def rocket_batch(h, X, U, diff_sol=True):
     return Y.reshape(12, B, order="F"), (DZ.reshape(12, 16, B, order="F") if diff_sol else None), st, it
 
 
-def soc_projection_batch(u_max, U, diff_sol=True):
-    """soc_projection(_gradient) on B controls: U (3, B) -> Z (10, B), DZ (10, 4, B) or None, status (B,), iters (B,)"""
+def soc_projection_batch(u_max, U, diff_sol=True, exact_boundary=False):
+    """soc_projection(_gradient) on B controls: U (3, B) -> Z (10, B), DZ (10, 4, B) or None, status (B,), iters (B,).
+    exact_boundary: the loop with its three rounding-decided places completed as exact arithmetic has them (ip_oracle.c::
+    od_oracle_set_exact_boundary); the default is the literal double-precision transcription"""
+    if exact_boundary:
+        lib().od_oracle_set_exact_boundary(1)
+        try:
+            return soc_projection_batch(u_max, U, diff_sol)
+        finally:
+            lib().od_oracle_set_exact_boundary(0)
     U = np.asfortranarray(U, dtype=np.float64)
     B = U.shape[1]
     Z = np.zeros(10 * B); DZ = np.zeros(40 * B) if diff_sol else None

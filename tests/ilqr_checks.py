@@ -242,9 +242,10 @@ def rocket_problem(lib, device, B, T, dtype=torch.float64, seed=0):
 def check_rollout_against_oracle(oracle, dyn, x1, U0, X, A, Bm, dtype, ntraj=64, h=0.05, u_max=12.5):
     """a projected rocket rollout of the device (X, and its linearisation A, Bm) against the oracle on the first `ntraj` trajectories
     (the oracle's rollouts and solves run batched under OpenMP), in the handle's precision:
-      * chained: the oracle's f_rocket_proj from x1 along the same controls -- the projected control is only kappa_tol = 1e-4
-        accurate by construction and its line search has rounding-level ties (parity_checks.check_rocket_sweep), so chained states
-        agree to that level (1e-3) in either precision;
+      * chained: the oracle's f_rocket_proj from x1 along the same controls, its projection with the rounding-decided places completed
+        as exact arithmetic has them (`exact_boundary`, like the device since round 6: parity_checks.check_rocket_sweep) -- all T steps
+        of every trajectory at 1e-6 in double (round 5, against the literal projection loop: 1e-3, the kappa_tol level of its
+        line-search ties), 5e-6 in single (60 chained steps of float rounding);
       * knot by knot, no path dependence left: f_rocket_proj / fx of the device on its own rollout states (independent knots, the
         solve the linearisation comes from) against the oracle's dynamics step from the same state with the control the DEVICE
         projected to -- at the north_star's bars in both precisions (1e-6 / 1e-4: the single-precision handle finishes its dynamics
@@ -253,11 +254,20 @@ def check_rollout_against_oracle(oracle, dyn, x1, U0, X, A, Bm, dtype, ntraj=64,
     nt = min(ntraj, x1.shape[1])
     Uq = U0.astype(np.float32).astype(np.float64) if dtype == torch.float32 else U0
     Xn, An = X.double().cpu().numpy()[:, :, :nt], A.double().cpu().numpy()[:, :, :, :nt]
-    Xo, _, so = oracle.rocket_rollout(h, u_max, x1[:, :nt], Uq[:, :, :nt], project=True)
+    oracle.lib().od_oracle_set_exact_boundary(1)
+    try:
+        Xo, _, so = oracle.rocket_rollout(h, u_max, x1[:, :nt], Uq[:, :, :nt], project=True)
+    finally:
+        oracle.lib().od_oracle_set_exact_boundary(0)
     okt = (so == 0x11).all(0)                                   # trajectories whose every oracle solve converged
     assert okt.mean() > 0.9
     err = np.abs(Xn - Xo).max(0) / np.maximum(1.0, np.abs(Xo).max(0))          # (T+1, nt)
-    assert err[:, okt].max() < 1e-3, float(err[:, okt].max())
+    chain_tol = 1e-6 if dtype == torch.float64 else 5e-6
+    # (a projection that is ill-conditioned in its own rounding -- 0.05 % of apex-heavy controls, check_rocket_sweep -- parts a whole
+    # trajectory from there on: at most one trajectory in 50 may, and only at the kappa_tol level)
+    bad = okt & (err.max(0) >= chain_tol)
+    assert bad.sum() <= nt // 50 and err[:, okt].max() < 1e-3, (str(dtype), int(bad.sum()), float(err[:, okt].max()))
+    okt = okt & ~bad
     # independent knots: the device's own states, all T * nt of them in one launch
     Xk = np.ascontiguousarray(Xn[:, :T].reshape(12, T * nt))
     Uk = np.ascontiguousarray(Uq[:, :, :nt].reshape(3, T * nt))
@@ -269,10 +279,11 @@ def check_rollout_against_oracle(oracle, dyn, x1, U0, X, A, Bm, dtype, ntraj=64,
     rel = lambda a, b: np.abs(a - b).reshape(-1, T * nt).max(0) / np.maximum(1.0, np.abs(b).reshape(-1, T * nt).max(0))
     es, ex = rel(Y, Yo)[ok], rel(DX, DZo[:, :12])[ok]
     assert es.max() < 1e-6 and ex.max() < 1e-4, (str(dtype), float(es.max()), float(ex.max()))
-    # (the rollout kernel and the independent-knot kernel are two compilations of the same solve: where their projections take
-    # different line-search paths they differ at the projection's kappa_tol level, like device and oracle do)
+    # (the rollout kernel and the independent-knot kernel are two compilations of the same solve; round 5 allowed them the kappa_tol
+    # level of the projection's line-search ties, 1e-3 -- the ties are gone)
     Xn1 = Xn[:, 1:].reshape(12, T * nt)
-    assert rel(Y, Xn1)[ok].max() <= 1e-3
+    two = rel(Y, Xn1)[ok]
+    assert (two > chain_tol).sum() <= max(1, ok.sum() // 2000) and two.max() <= 1e-3, (str(dtype), int((two > chain_tol).sum()), float(two.max()))
     # the linearisation IS that solve
     Ak = An.reshape(12, 12, T * nt)
     assert rel(DX, Ak)[ok].max() <= 1e-6
@@ -791,9 +802,13 @@ ORACLE_CASES = {
     # examples/acrobot.jl AS SHIPPED (`:nominal`: no joint limits, smooth dynamics)
     "acrobot_nominal": dict(T=100, kw=dict(max_iter=50, max_al_iter=20, obj_tol=1e-5, con_tol=1e-3), tolJ=1e-8, need=None),
     "rocket": dict(T=20, kw=dict(max_iter=10, max_al_iter=1, obj_tol=1e-7, con_tol=1e-4), tolJ=1e-8, need=None),
-    # with the thrust-cone projection on the path every control is a kappa_tol = 1e-4 accurate end point of a line search that
-    # compares rounding noise (parity_checks.check_rocket_sweep): costs agree to that level until an Armijo test lands on the other side
-    "rocket_projected": dict(T=20, kw=dict(max_iter=10, max_al_iter=1, obj_tol=1e-7, con_tol=1e-4), tolJ=2e-3, need=2),
+    # with the thrust-cone projection on the path.  Round 5 compared against the LITERAL oracle projection, whose eps_min = 0 line search
+    # compares rounding noise: costs agreed to kappa_tol level (2e-3) until an Armijo test landed on the other side, 8-10 of 10 iterations.
+    # Round 6: device and oracle both complete the projection's rounding-decided places as exact arithmetic has them
+    # (parity_checks.check_rocket_sweep, oracle `exact_boundary`): costs to 1e-8 while the decisions agree, and they agree in every
+    # iteration on all but the odd problem whose projection is ill-conditioned in its own rounding (`all_frac`: the share of problems
+    # that must agree to the end; the rest for `need` leading iterations)
+    "rocket_projected": dict(T=20, kw=dict(max_iter=10, max_al_iter=1, obj_tol=1e-7, con_tol=1e-4), tolJ=1e-8, need=3, all_frac=0.74, exact_boundary=True),
 }
 
 
@@ -804,6 +819,14 @@ def check_against_numpy_oracle(oracle, lib, device, case, B=8, seed=1):
     from oracle import ilqr_np as N
     from optimization_dynamics_amd import rocket as rk
     cfg = ORACLE_CASES[case]
+    if cfg.get("exact_boundary") and not getattr(check_against_numpy_oracle, "_inside", False):
+        oracle.lib().od_oracle_set_exact_boundary(1)
+        check_against_numpy_oracle._inside = True
+        try:
+            return check_against_numpy_oracle(oracle, lib, device, case, B=B, seed=seed)
+        finally:
+            check_against_numpy_oracle._inside = False
+            oracle.lib().od_oracle_set_exact_boundary(0)
     T, kw = cfg["T"], cfg["kw"]
     roll = None
     if case == "cartpole":
@@ -866,6 +889,10 @@ def check_against_numpy_oracle(oracle, lib, device, case, B=8, seed=1):
             # in is decided after the paths have parted: same constraint flag, objectives of one order, iteration counts of one order)
             assert 0.4 * abs(Jo) <= abs(Jd) <= 2.5 * abs(Jo), (case, b, Jd, Jo)
             assert abs(len(L) - len(rows)) <= max(3, 0.5 * len(L)), (case, b, len(L), len(rows))
+    if cfg.get("all_frac"):
+        full = sum(int(a == o == d_) for a, o, d_ in zip(stats["agreeing_iterations"], stats["iterations_oracle"], stats["iterations_device"]))
+        stats["problems_agreeing_in_every_decision"] = full
+        assert full >= cfg["all_frac"] * B, (case, "problems agreeing in every decision", full, B)
     return stats
 
 

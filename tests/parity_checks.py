@@ -366,17 +366,22 @@ def check_ls_kat(lib, device):
     assert np.allclose(theta.reshape(2, 3, order="F"), [[1, 1, 0], [0, 1, 1]], atol=1e-10)
 
 
-# The thrust-cone projection runs with eps_min = 0 (tau = 1, src/models/rocket/dynamics.jl:81): from its first full step on
-# the equality residual is rounding noise and the line-search test (r_cand <= r_vio || k_cand <= k_vio) compares noise, so
-# two correct double-precision implementations can accept different step lengths.  Settled with the binary128 arbiter
-# (oracle/arbiter.c::od_arbiter_soc_projection; the equality rows are linear, so exact arithmetic always accepts the
-# first trial): measured on the MI355X over 6000 controls (tools/proj_paths.py -> profiles/r3_projection_paths.json) the
-# device follows the exact path to 1e-7 on 85.4-86.3 % of them and the oracle on 91.6-93.3 %; off the path every end point
-# is within 3.3e-4 of the exact path's (the solver's own kappa_tol = 1e-4 level), and all of them -- exact path included --
-# within 4.3e-3 of the closed-form Euclidean projection (what a kappa_tol-accurate interior point is worth near the apex).
-PROJ_OFF_PATH_RATE = {torch.float64: 0.15, torch.float32: 0.002}       # measured upper rates (fp32: "path" = 2e-3)
-PROJ_PATH_TOL = {torch.float64: 1e-7, torch.float32: 2e-3}
-PROJ_OFF_PATH_DEV = {torch.float64: 5e-4, torch.float32: 6e-3}
+# The thrust-cone projection runs with eps_min = 0 (tau = 1, src/models/rocket/dynamics.jl:81): every step goes ALL the way to the
+# boundary of an orthant, and from its first full step on the equality residual is rounding noise.  A literal double-precision
+# transcription of the loop (the oracle's default, and the reference itself on whatever BLAS it runs) then reads rounding noise in three
+# places: where the blocking variable lands (exactly zero in exact arithmetic; +-1e-17 in floating point), the sign of the next affine
+# direction of a variable that sits at zero (zero times something), and the line search's `r_c <= r_vio` between two residuals that are
+# both exactly zero.  Settled with the binary128 arbiter (oracle/arbiter.c::od_arbiter_soc_projection: exact acceptance, the blocking
+# variable completed to zero, boundary rows solved exactly) -- the exact-arithmetic path.  Round 6: the device completes the same three
+# places as exact arithmetic has them (csrc/od_rocket_proj_direct.h: SNAP_BLOCKING, LINEAR_EQ_ROWS) and follows that path to 1e-7 on
+# 99.95 % of apex-heavy controls, in both precisions (a single-precision handle solves the projection in double under
+# od_set_mixed_precision, the default); the literal oracle on 95.5 %; the oracle with the same completions (oracle.soc_projection_batch(...,
+# exact_boundary=True): double, dense pivoted LU) on 99.95 %.  Round 5, before: 86 % on the MI355X (profiles/r5_rocket_parity_sweep.json).
+# What stays off the path are controls whose solve is ill-conditioned in its own rounding (end points within 1e-5 of the path's).
+PROJ_OFF_PATH_RATE = {torch.float64: 0.004, torch.float32: 0.004}      # measured 0.0005 (host build, exact and device-like arithmetic)
+PROJ_PATH_TOL = {torch.float64: 1e-7, torch.float32: 1e-6}             # (single: the double solve's result rounded to float, 6e-8)
+PROJ_OFF_PATH_DEV = {torch.float64: 1e-4, torch.float32: 1e-4}         # measured 9e-6
+PROJ_ON_PATH_MIN = 0.99
 
 
 def projection_paths(oracle, U, UP, dtype=torch.float64):
@@ -422,6 +427,20 @@ def check_rocket(oracle, lib, device, B, dtype=torch.float64):
             assert np.abs(DX1[:, :, b].double().cpu().numpy() - dz[:, :12]).max() < 2e-2 * max(1, np.abs(dz[:, :12]).max())
         assert e1 < 5e-4 and e2 < STATE_TOL, (e1, e2)
         print("rocket dynamics step, single precision: state error %.2e without / %.2e with the double-precision polish" % (e1, e2))
+        # the projection the same way: single precision throughout under od_set_mixed_precision(h, 0) -- what float iterates of this
+        # ill-conditioned path are worth (2e-3 of the double solve on all, 1e-6 on about two thirds) -- and the double-precision handle's
+        # control to float resolution with the switch on
+        lib.check(lib.cdll.od_set_mixed_precision(info._h, 0))
+        Zf, _, stf, _ = info.project_full(torch.tensor(U), grads=False)
+        lib.check(lib.cdll.od_set_mixed_precision(info._h, 1))
+        Zm, _, stm, _ = info.project_full(torch.tensor(U), grads=False)
+        Zd, _, std, _ = rk.RocketInfo(models.rocket, 12.5, 0.05, dtype=torch.float64, device=device, lib=lib).project_full(torch.tensor(U), grads=False)
+        Zf, Zm, Zd = Zf.double().cpu().numpy(), Zm.double().cpu().numpy(), Zd.cpu().numpy()
+        cv = ((stf.cpu().numpy() & 0x10) != 0) & ((stm.cpu().numpy() & 0x10) != 0) & ((std.cpu().numpy() & 0x10) != 0)
+        scu = np.maximum(1.0, np.abs(Zd[:3]).max(0))
+        ef, em = (np.abs(Zf[:3] - Zd[:3]).max(0) / scu)[cv], (np.abs(Zm[:3] - Zd[:3]).max(0) / scu)[cv]
+        assert cv.sum() >= B - 2 and em.max() < 2e-7 and ef.max() < 6e-3 and (ef > 1e-6).any(), (float(em.max()), float(ef.max()))
+        print("thrust-cone projection, single-precision handle vs double-precision handle: %.2e without / %.2e with mixed precision" % (ef.max(), em.max()))
     if dtype == torch.float64:
         d = np.zeros(12); dxs = np.zeros((12, 12)); dus = np.zeros((12, 3))
         rk.f_rocket_proj(d, info, X[:, 0], U[:, 0], None)
@@ -1024,8 +1043,14 @@ def check_rocket_sweep(oracle, lib, device, B, seed, dtype=torch.float64, u_max=
     # the other stalls (seen once per 8192 controls on other seeds).  Its size and the disagreements inside it are bounded and recorded.
     plain_o, plain_d = conv_o & (itpo < 30), conv_d & (itp < 30)
     stalled = ~(plain_o & plain_d)
-    # (how many controls of a draw enter the stalled population is a count with Poisson spread: 0.2-1 % of these apex-heavy inputs)
-    assert stalled.sum() <= max(8, B // 50), (row["dtype"], int(stalled.sum()))
+    # How many controls of a draw enter the stalled population is a property of the algorithm in exact arithmetic (0.1-0.3 % of these
+    # apex-heavy inputs): the binary128 path stalls on the same controls.  The device's count is held to the arbiter's own on the same
+    # inputs -- the same number up to the few solves that leave a stall by rounding drift -- not to a constant fitted to seeds.
+    Ex, okex, itex = oracle.arbiter_soc_projection_batch(u_max, U, True)
+    stalled_exact = ~((okex == 1) & (itex < 30))
+    row.update(proj_stalled_exact_path=int(stalled_exact.sum()))
+    assert abs(int(stalled.sum()) - int(stalled_exact.sum())) <= 3 + int(0.25 * stalled_exact.sum()), (row["dtype"], int(stalled.sum()), int(stalled_exact.sum()))
+    assert (stalled & ~stalled_exact).sum() <= 3 + int(0.25 * stalled_exact.sum()), (row["dtype"], "stalls where exact arithmetic does not stall", int((stalled & ~stalled_exact).sum()))
     ndis = int((conv_d != conv_o).sum())
     # (single precision: the float solve stops at r_tol = 1e-4 where the double one asks for 1e-8 -- a few more disagreements near the apex)
     assert ndis <= (max(3, B // 1000) if f64 else max(4, B // 250)), (row["dtype"], "status disagreements", ndis)
@@ -1044,7 +1069,7 @@ def check_rocket_sweep(oracle, lib, device, B, seed, dtype=torch.float64, u_max=
     excess = cross[fin] - 2.0 * expl[fin] - (0.0 if f64 else 1.0) * bound[fin]
     assert excess.max() < GRAD_TOL, ("projection gradient, device vs oracle beyond what their end points explain", float(excess.max()))
     # the projected control
-    E, oke, ite = oracle.arbiter_soc_projection_batch(u_max, U, True)
+    E, oke, ite = Ex, okex, itex
     Pc = oracle.project_thrust_cone_batch(U, u_max)
     scp = np.maximum(1.0, np.abs(Pc).max(0))
     dpath = np.abs(Z[:3] - E[:3]).max(0) / scp
@@ -1074,9 +1099,22 @@ def check_rocket_sweep(oracle, lib, device, B, seed, dtype=torch.float64, u_max=
     row.update(proj_device_vs_closed_form_max=float((np.abs(Z[:3] - Pc).max(0) / scp)[use].max()))
     row.update(proj_end_point_r_vio_max=float(rv[conv_d].max()), proj_end_point_k_vio_max=float(kv[conv_d].max()),
                proj_exact_path_vs_closed_form_max=float((np.abs(E[:3] - Pc).max(0) / scp)[use].max()))
+    # the device follows the exact-arithmetic path (round 6): a bar, both precisions
+    assert on[use].mean() >= PROJ_ON_PATH_MIN, (row["dtype"], "controls on the exact-arithmetic path", float(on[use].mean()))
+    assert dpath[use & ~on].max(initial=0.0) < PROJ_OFF_PATH_DEV[dtype], float(dpath[use & ~on].max(initial=0.0))
     ctrl = np.abs(Z[:3] - Zo[:3]).max(0) / scp
     same_path = use & on & (opath < PROJ_PATH_TOL[torch.float64])
-    assert ctrl[same_path].max(initial=0.0) < (STATE_TOL if f64 else 3e-3), float(ctrl[same_path].max())
+    assert ctrl[same_path].max(initial=0.0) < STATE_TOL, float(ctrl[same_path].max())
+    # ... and agrees at 1e-6 with a second double-precision implementation of that path (the oracle's loop -- dense pivoted LU -- with the
+    # three rounding-decided places completed as exact arithmetic has them), iteration for iteration
+    Zx, DPx, stx, itx = oracle.soc_projection_batch(u_max, U, True, exact_boundary=True)
+    usex = both & (stx == 1)
+    cx = np.abs(Z[:3] - Zx[:3]).max(0) / scp
+    assert (cx[usex] < STATE_TOL).mean() >= 0.998 and cx[usex].max() < PROJ_OFF_PATH_DEV[dtype], (float((cx[usex] < STATE_TOL).mean()), float(cx[usex].max()))
+    assert (itp[usex] == itx[usex]).mean() >= 0.998, float((itp[usex] == itx[usex]).mean())
+    assert ((stx == 1) != conv_d).sum() <= 3 + int(0.25 * stalled_exact.sum()), int(((stx == 1) != conv_d).sum())
+    row.update(proj_control_vs_exact_boundary_oracle_within_1e6=float((cx[usex] < STATE_TOL).mean()), proj_control_vs_exact_boundary_oracle_max=float(cx[usex].max()),
+               proj_iterations_equal_exact_boundary_oracle=float((itp[usex] == itx[usex]).mean()))
     row.update(proj_converged_device=int(conv_d.sum()), proj_converged_oracle=int(conv_o.sum()), proj_stalled=int(stalled.sum()),
                proj_status_disagreements_on_stalled=int((stalled & (conv_d != conv_o)).sum()),
                proj_arbitrated=int(fin.sum()), proj_on_exact_path_device=float(on[use].mean()), proj_on_exact_path_oracle=float((opath[use] < 1e-7).mean()),
@@ -1114,4 +1152,28 @@ def check_rocket_sweep(oracle, lib, device, B, seed, dtype=torch.float64, u_max=
     eu = eu[cmp_u]
     row.update(chain_converged=int(okc.sum()), chain_state_rel_max=float(es.max()), chain_fx_rel_max=float(ex.max()), chain_fu_rel_max=float(eu.max()),
                chain_same_projection_in_both_kernels=int(same.sum()))
+    # (4) end to end against the ORACLE'S OWN chain (round 6): its projection, its dynamics step at the control IT projected to, its
+    # projection gradient in the product -- nothing of the device fed back -- on every knot where the two projections follow the same path
+    # (device within 1e-6 of the oracle's control: all but ~0.05 % against the exact-boundary oracle, the ~95 % on which the literal
+    # oracle stays on the exact-arithmetic path against the literal one).  f and fx at 1e-6 / 1e-4 outright; fu at 1e-4 beyond what the
+    # exact (binary128) projection gradients at the two end points differ by, times the dynamics' amplification (an end point 1e-7 away
+    # next to the apex has another gradient: cond up to 1e9).
+    for tag, Zr, DPr, okr in (("exact_boundary_oracle", Zx, DPx, stx == 1), ("literal_oracle", Zo, DPo, conv_o & (opath < PROJ_PATH_TOL[torch.float64]))):
+        e2e = okc & conv_d & okr & (np.abs(UP - Zr[:3]).max(0) / scp < STATE_TOL)
+        Yo3, DZo3, sto3, _ = oracle.rocket_batch(h, X, Zr[:3], True)
+        e2e = e2e & (sto3 == 1)
+        Er, _ = oracle.arbiter_gradient_batch("rocket_projection", Zr, TH)
+        expl_r = g(Ed, Er[:3, :3])
+        e2e = e2e & np.isfinite(expl_r) & np.isfinite(dev)
+        chain_o = np.einsum("ikb,kcb->icb", DZo3[:, 12:15], DPr[:3, :3])
+        es4, ex4, eu4 = rel(Y, Yo3, 0), rel(DX, DZo3[:, :12], 0), rel(DU, chain_o, 0)
+        amp4 = np.abs(DZo3[:, 12:15]).reshape(-1, B).max(0) * sc / np.maximum(1.0, np.abs(chain_o).reshape(-1, B).max(0))
+        tol4 = GRAD_TOL + (2.0 * expl_r + (0.0 if f64 else 4.0) * np.where(np.isfinite(bound), bound, 0.0)) * amp4
+        frac = e2e.sum() / max(1, (okc & conv_d).sum())
+        assert frac >= (0.995 if tag == "exact_boundary_oracle" else 0.90), (row["dtype"], tag, "knots compared end to end", float(frac))
+        assert es4[e2e].max() < STATE_TOL and ex4[e2e].max() < GRAD_TOL, (row["dtype"], tag, float(es4[e2e].max()), float(ex4[e2e].max()))
+        assert (eu4[e2e] <= tol4[e2e]).all(), (row["dtype"], tag, "fu_rocket_proj end to end", float((eu4[e2e] / tol4[e2e]).max()))
+        row.update({"e2e_%s_knots" % tag: int(e2e.sum()), "e2e_%s_fraction" % tag: float(frac), "e2e_%s_state_rel_max" % tag: float(es4[e2e].max()),
+                    "e2e_%s_fx_rel_max" % tag: float(ex4[e2e].max()), "e2e_%s_fu_rel_max" % tag: float(eu4[e2e].max()),
+                    "e2e_%s_fu_within_1e4_outright" % tag: float((eu4[e2e] < GRAD_TOL).mean())})
     return row
