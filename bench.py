@@ -198,7 +198,7 @@ def main():
     ap.add_argument("--coop", type=int, default=0, help="cooperative solve pass: 0 automatic, 1 never, 2 always")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the multi-rank code path even with ONE rank: torch.distributed.run --nproc-per-node 1, init_process_group "
-                         "(nccl = RCCL on the GPU), barriers, the max-over-ranks all-reduce and (with --gather) all_gather_into_tensor -- so "
+                         "(nccl = RCCL on the GPU), barriers, the max-over-ranks all-reduce and (with --gather) od_allgather_compact -- so "
                          "that every line of the N > 1 path has executed on whatever single MI355X is at hand (tests/test_distributed.py)")
     ap.add_argument("--test-emu-lib", default=None,
                     help="TEST HARNESS ONLY (tests/test_distributed.py): run the ranks on CPU over gloo against the host-emulation build")
@@ -247,6 +247,14 @@ def main():
     from optimization_dynamics_amd.parallel import shard_range
     stream = None if emu else torch.cuda.current_stream(dev)
 
+    comm = None
+    if args.gather and dist is not None:
+        from optimization_dynamics_amd.parallel import Communicator
+        box = [Communicator.unique_id(im.lib) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)            # the 128-byte id, out of band (a Julia host: a file or a socket)
+        comm = Communicator(im, box[0], rank, world)
+        assert comm.world == world and comm.rank == rank
+
     def inputs_for(mode):
         """(lo, hi) of this rank in the global workload"""
         if mode == "weak":
@@ -269,11 +277,10 @@ def main():
                 X, A, Bm, st, it, out = im.rollout(x1d, Ud, out=out)
                 return st, it
             X, G, st, it, out = im.rollout_compact(x1d, Ud, out=out)
-            if args.gather and dist is not None:
-                if gather_bufs is None:
-                    gather_bufs = [torch.empty(world * t.numel(), dtype=t.dtype, device=dev) for t in (out["X"], out["G"])]
-                for buf, t in zip(gather_bufs, (out["X"], out["G"])):
-                    dist.all_gather_into_tensor(buf, t.reshape(-1))
+            if comm is not None:
+                # the product's collective: od_allgather_compact (two ncclAllGather on the handle's stream, behind the C ABI a Julia
+                # process per GPU would call) -- not torch.distributed
+                _, _, gather_bufs = comm.gather_compact(out, gather_bufs)
             return st, it
 
         for _ in range(args.warmup):
@@ -302,8 +309,8 @@ def main():
         kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else elapsed / args.steps * 1e3
         if dump and rank == 0 and gather_bufs is not None:
             Bl = hi - lo
-            Xg = gather_bufs[0].view(world, 8, T + 1, Bl).movedim(0, -2).reshape(8, T + 1, world * Bl)
-            Gg = gather_bufs[1].view(world, 10, 4, T, Bl).movedim(0, -2).reshape(10, 4, T, world * Bl).transpose(0, 1)
+            Xg = gather_bufs[0].reshape(world, 8, T + 1, Bl).movedim(0, -2).reshape(8, T + 1, world * Bl)
+            Gg = gather_bufs[1].reshape(world, 10, 4, T, Bl).movedim(0, -2).reshape(10, 4, T, world * Bl).transpose(0, 1)
             np.savez(dump, X=Xg.cpu().numpy(), G=Gg.cpu().numpy())
         return elapsed, kernel_ms, st, it, hi - lo
 
@@ -400,7 +407,8 @@ def main():
             "metric": "contact-implicit steps+grads/sec, hopper T=%d batch=%d%s" % (T, args.batch, "" if args.scaling == "weak" else " (fixed total, sharded)"),
             "value": value, "unit": "steps+grads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
-            "ranks_seen": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else "none (single process)"),
+            "ranks_seen": (comm.world if comm is not None else dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else "none (single process)"),
+            "collective": ("od_allgather_compact: ncclAllGather x 2 behind the C ABI (od_comm_*), ranks_seen = ncclCommCount" if comm is not None else None),
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "hopper (RoboDojo path-following contact), T=%d, batch=%d rollouts %s, "
                                    "h=0.05, kappa_eval=1e-4, kappa_grad=1e-3, r_tol=1e-8; od_rollout_compact = f+fx+fu per knot (q3, dq3/d(q1,q2,u))"

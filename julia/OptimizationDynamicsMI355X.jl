@@ -21,9 +21,17 @@ export ImplicitDynamics, f, fx, fu, state_to_configuration, GradientBundle, fx_g
        soc_projection, soc_projection_gradient, ffxfu!,
        od_step_grad!, od_rollout!, od_rollout_compact!, od_rocket!, od_soc_project!, od_step_full!, model_indices,
        ILQRSolver, set_constraints!, set_parameter_stage!, set_gradient_bundle!, get_status!, get_trace!, initialize!, iterate!, al_update!,
-       solve!, get_trajectory!
+       solve!, get_trajectory!,
+       Communicator, comm_unique_id, allgather_compact!, allgather!
 
 const LIB = get(ENV, "OD_MI355X_LIB", joinpath(@__DIR__, "..", "optimization_dynamics_amd", "libod_mi355x.so"))
+
+# include/od_mi355x.h: OD_ABI_VERSION this shim was written against (the struct mirrors below, the defaults the wrappers rely on)
+const ABI_VERSION = 101
+function __init__()
+    got = ccall((:od_version, LIB), Cint, ())
+    got == ABI_VERSION || error("libod_mi355x reports ABI version $got, this shim was written against $ABI_VERSION: rebuild the library")
+end
 
 const MODEL_IDS = Dict(:acrobot_impact => 0, :acrobot_nominal => 1, :cartpole_friction => 2,
                        :cartpole_frictionless => 3, :planarpush => 4, :rocket => 5,
@@ -273,6 +281,37 @@ function od_rollout_compact!(im::ImplicitDynamics, B, T, x1, U, X, G)
     check(ccall((:od_rollout_compact, LIB), Cint, (Ptr{Cvoid}, Clong, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}, Ptr{Cint}),
                 im.h, B, T, pointer(x1), pointer(U), pointer(X), pointer(G), C_NULL, C_NULL))
 end
+
+# ---- one Julia process per GPU (SURVEY.md 8(e)): rollouts sharded, the compact linearisation gathered over RCCL behind the C ABI ----------
+# Rank 0 makes the id and hands its 128 bytes to the other processes (a file, a socket, Distributed.jl); every process then creates its
+# communicator -- a collective call -- on the device its ImplicitDynamics handle lives on (INTEGRATION.md shows the eight-process loop).
+mutable struct Communicator
+    c::Ptr{Cvoid}
+    world::Int
+    rank::Int
+end
+function comm_unique_id()
+    id = zeros(UInt8, 128)                         # OD_COMM_ID_BYTES
+    check(ccall((:od_comm_unique_id, LIB), Cint, (Ptr{Cvoid},), id))
+    return id
+end
+function Communicator(im::ImplicitDynamics, id::Vector{UInt8}, rank::Integer, world::Integer)
+    length(id) == 128 || error("the id of comm_unique_id() has 128 bytes")
+    hd = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:od_comm_create, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Ref{Ptr{Cvoid}}), im.h, id, rank, world, hd))
+    w = Ref{Cint}(0); r = Ref{Cint}(0)
+    check(ccall((:od_comm_info, LIB), Cint, (Ptr{Cvoid}, Ref{Cint}, Ref{Cint}, Ptr{Cint}), hd[], w, r, C_NULL))
+    comm = Communicator(hd[], w[], r[])
+    finalizer(x -> ccall((:od_comm_destroy, LIB), Cint, (Ptr{Cvoid},), x.c), comm)
+    return comm
+end
+"all-gather of od_rollout_compact!'s X and G (device arrays, every rank the same B and T): X_all / G_all hold `world` blocks, block r = rank r's array"
+allgather_compact!(im::ImplicitDynamics, comm::Communicator, B, T, X, G, X_all, G_all) =
+    check(ccall((:od_allgather_compact, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Clong, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                im.h, comm.c, B, T, pointer(X), pointer(G), pointer(X_all), pointer(G_all)))
+"all-gather of any device buffer of `bytes` bytes per rank (e.g. the gains of a backward pass)"
+allgather!(im::ImplicitDynamics, comm::Communicator, send, recv, bytes::Integer) =
+    check(ccall((:od_comm_allgather, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), im.h, comm.c, pointer(send), pointer(recv), bytes))
 
 "whole solution on device arrays (contact impulses and their sensitivities): Z nz x B, DZ (nz*(2nq+nu)) x B; rows via model_indices"
 function od_step_full!(im::ImplicitDynamics, B, X, U, Z, DZ)

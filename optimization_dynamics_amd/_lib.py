@@ -129,7 +129,17 @@ SIGNATURES = {
     "od_rocket_host": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _IP]),
     "od_soc_project_host": (C.c_int, [_VP, _VP, _VP, _VP, _IP]),
     "od_bundle_grad_host": (C.c_int, [_VP, C.c_int, _VP, _VP, _VP, _VP, _IP]),
+    "od_comm_unique_id": (C.c_int, [_VP]),
+    "od_comm_create": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "od_comm_info": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "od_comm_destroy": (C.c_int, [_VP]),
+    "od_allgather_compact": (C.c_int, [_VP, _VP, C.c_long, C.c_int, _VP, _VP, _VP, _VP]),
+    "od_comm_allgather": (C.c_int, [_VP, _VP, _VP, _VP, C.c_size_t]),
 }
+
+# include/od_mi355x.h: OD_ABI_VERSION this mirror was written against (struct layouts above, defaults the wrappers rely on)
+ABI_VERSION = 101
+COMM_ID_BYTES = 128
 
 
 class Library:
@@ -146,6 +156,10 @@ class Library:
             fn = getattr(self.cdll, name)   # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        got = self.cdll.od_version()
+        if got != ABI_VERSION:
+            raise ODError("%s reports ABI version %d, this binding was written against %d (include/od_mi355x.h: OD_ABI_VERSION): rebuild the "
+                          "library -- a stale one reads od_ilqr_options of another size" % (self.path, got, ABI_VERSION))
         # the library's own registry: the eight models of the reference plus whatever the generator added (--add)
         self.model_ids = {self.cdll.od_model_name(i).decode(): i for i in range(self.cdll.od_num_models())}
 

@@ -5,8 +5,70 @@ exchange the path can have is an all-gather of the per-knot linearisation for an
 of the reference's callbacks are those numbers plus constant rows (src/dynamics.jl:105-111,125) and 2.4x the bytes --
 as one all_gather_into_tensor per array into a preallocated buffer, read through a view (no concatenation copy).
 The reference has no distributed code at all (single Julia process)."""
+import ctypes as C
+
 import torch
 import torch.distributed as dist
+
+from . import _lib
+
+
+class Communicator:
+    """od_comm_* (include/od_mi355x.h): the all-gather of the compact linearisation over RCCL behind the C ABI, on the handle's stream --
+    what a Julia process per GPU calls; this class is the same calls from Python.  `unique_id()` on rank 0, the 128
+    bytes to every rank by whatever the host has (a file, a socket, torch.distributed), then `Communicator(im, id, rank, world)` on all
+    ranks (a collective call).  `gather_compact(out)` -> X_all (world, 2nq, T+1, B), G_all (world, nq, 2nq+nu, T, B): block r is rank
+    r's arrays."""
+
+    @staticmethod
+    def unique_id(lib=None):
+        lib = lib or _lib.default_library()
+        buf = (C.c_char * _lib.COMM_ID_BYTES)()
+        lib.check(lib.cdll.od_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, im, uid, rank, world):
+        assert len(uid) == _lib.COMM_ID_BYTES
+        self.im, self.lib = im, im.lib
+        h = C.c_void_p()
+        self.lib.check(self.lib.cdll.od_comm_create(im._h, C.c_char_p(uid), int(rank), int(world), C.byref(h)))
+        self._c = h
+        w, r, d = C.c_int(), C.c_int(), C.c_int()
+        self.lib.check(self.lib.cdll.od_comm_info(self._c, C.byref(w), C.byref(r), C.byref(d)))
+        self.world, self.rank, self.device_index = w.value, r.value, d.value      # as the communicator reports them (ncclCommCount / ncclCommUserRank)
+
+    def gather_compact(self, out, bufs=None):
+        """`out`: the buffer dict ImplicitDynamics.rollout_compact returns last (X: 2nq x (T+1) x B; G: the raw nq (2nq+nu) x T x B
+        array, column-major per knot) -> X_all (world, 2nq, T+1, B), G_all (world, nq, 2nq+nu, T, B) (a view), bufs (pass back in to
+        reuse); asynchronous on the handle's stream (the current torch stream: ImplicitDynamics sets it per call)"""
+        X, G = out["X"], out["G"]
+        nq = self.im.model.nq
+        T, B = G.shape[-2], G.shape[-1]
+        if bufs is None:
+            bufs = (torch.empty((self.world,) + tuple(X.shape), dtype=X.dtype, device=X.device), torch.empty((self.world,) + tuple(G.shape), dtype=G.dtype, device=G.device))
+        self.im._use_current_stream()
+        self.lib.check(self.lib.cdll.od_allgather_compact(self.im._h, self._c, B, T, X.data_ptr(), G.data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr()))
+        return bufs[0], bufs[1].view(self.world, G.shape[0] // nq, nq, T, B).transpose(1, 2), bufs
+
+    def gather(self, t, out=None):
+        """any contiguous device tensor -> (world,) + t.shape"""
+        t = t.contiguous()
+        if out is None:
+            out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        self.im._use_current_stream()
+        self.lib.check(self.lib.cdll.od_comm_allgather(self.im._h, self._c, t.data_ptr(), out.data_ptr(), t.numel() * t.element_size()))
+        return out
+
+    def close(self):
+        if getattr(self, "_c", None):
+            self.lib.cdll.od_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shard_range(n, world, rank):

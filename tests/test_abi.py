@@ -100,7 +100,7 @@ def _null_fuzz(emu_lib, device):
     import parity_checks as P
     cd = emu_lib.cdll
     queries = {"od_version", "od_num_models", "od_model_name", "od_last_error", "od_model_indices", "od_model_dims",
-               "od_raw_grad_dims", "od_uses_cooperative", "od_bundle_workspace_bytes", "od_destroy", "od_ilqr_destroy",
+               "od_raw_grad_dims", "od_uses_cooperative", "od_bundle_workspace_bytes", "od_destroy", "od_ilqr_destroy", "od_comm_destroy",
                "od_num_constraints", "od_constraint_name", "od_constraint_dims"}
     for name in sorted(_lib.SIGNATURES):
         fn = getattr(cd, name)
@@ -121,6 +121,8 @@ def _null_fuzz(emu_lib, device):
                 continue
             if name.startswith("od_ilqr_") and name not in ("od_ilqr_create", "od_ilqr_backward"):
                 continue                                    # (their first argument is a solver object, not a handle: below)
+            if name in ("od_comm_info", "od_comm_destroy", "od_comm_unique_id"):
+                continue                                    # (first argument: a communicator / the id buffer: below)
             args = _zero_args(fn, h)
             for i, t in enumerate(at):                      # a batch of 4 problems / knots, null buffers
                 if i > 0 and t is C.c_long:
@@ -139,6 +141,18 @@ def _null_fuzz(emu_lib, device):
         assert cd.od_ilqr_get_info(s, None) < 0
         assert cd.od_ilqr_set_constraints(s, 17, 0, None, None, None, 0, 0, None, None) < 0 and cd.od_ilqr_set_constraints(s, 2, 0, None, None, None, 0, 0, None, None) < 0
         assert cd.od_ilqr_destroy(s) == 0
+        # a live communicator (one rank), null buffers
+        if hasattr(emu_lib, "path") and (device == "cpu" or os.environ.get("OD_TEST_RCCL", "1") == "1"):
+            uid = (C.c_ubyte * 128)()
+            assert cd.od_comm_unique_id(uid) == 0, cd.od_last_error()
+            cm = C.c_void_p()
+            assert cd.od_comm_create(h, uid, 0, 1, C.byref(cm)) == 0, cd.od_last_error()
+            assert cd.od_comm_create(h, uid, 0, 1, None) < 0 and cd.od_comm_create(h, uid, 1, 1, C.byref(C.c_void_p())) < 0
+            assert cd.od_comm_info(cm, None, None, None) == 0
+            assert cd.od_comm_allgather(h, cm, None, None, 16) < 0 and cd.od_comm_allgather(h, cm, None, None, 0) == 0
+            r = cd.od_allgather_compact(h, cm, 4, 3, None, None, None, None)
+            assert r < 0                                        # (hopper: nothing to gather; rocket: not a model with a compact linearisation)
+            assert cd.od_comm_destroy(cm) == 0
 
 
 def test_null_arguments_are_error_codes_not_crashes(emu_lib):

@@ -186,11 +186,11 @@ def test_workload_slices_are_consistent():
 
 def test_bench_force_dist_runs_the_multi_rank_path_with_one_rank(emu_lib, tmp_path):
     """`bench.py --force-dist --gather`: ONE rank under torch.distributed.run, process group initialised, barriers, max-over-ranks
-    all-reduce and all_gather_into_tensor all executed (gloo + host build here; the -m gpu twin below runs the same lines over
-    RCCL on the MI355X) -- and the gathered result is the plain rollout"""
+    all-reduce and od_allgather_compact (the product's collective behind the C ABI, csrc/od_comm.inc; here over the harness stand-in
+    for librccl, in the -m gpu twin below over RCCL on the MI355X) all executed -- and the gathered result is the plain rollout"""
     dump = str(tmp_path / "forced.npz")
     rec = _run_bench(emu_lib, ["--force-dist", "--gather", "--test-dump", dump])
-    assert rec["n_gpus"] == 1 and rec["ranks_seen"] == 1 and rec["backend"] == "gloo"
+    assert rec["n_gpus"] == 1 and rec["ranks_seen"] == 1 and rec["backend"] == "gloo" and "od_allgather_compact" in rec["collective"]
     assert "all-gather" in rec["config"]["parallelism"] and rec["value"] > 0
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -205,8 +205,9 @@ def test_bench_force_dist_runs_the_multi_rank_path_with_one_rank(emu_lib, tmp_pa
 @pytest.mark.gpu
 def test_bench_force_dist_over_rccl_gpu(tmp_path):
     """the multi-rank path of bench.py on the hardware: torch.distributed.run --nproc-per-node 1, backend nccl (= RCCL), --gather --
-    init_process_group, barrier, all_reduce(MAX) and all_gather_into_tensor on device tensors; the record says so, and the
-    gathered linearisation equals the single-process rollout bit for bit"""
+    init_process_group, barrier, all_reduce(MAX) through torch.distributed, and the data path's collective through the C ABI:
+    od_comm_create (ncclCommInitRank) + od_allgather_compact (two ncclAllGather on the handle's stream) on device arrays; the record
+    says so (ranks_seen = ncclCommCount), and the gathered linearisation equals the single-process rollout bit for bit"""
     import json
     import subprocess
     dump = str(tmp_path / "rccl.npz")
@@ -223,7 +224,7 @@ def test_bench_force_dist_over_rccl_gpu(tmp_path):
         pytest.skip("torch.distributed / RCCL could not be brought up on this box: " + out.stderr.strip().splitlines()[-1][:300])
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert rec["n_gpus"] == 1 and rec["ranks_seen"] == 1 and rec["backend"] == "nccl", rec
+    assert rec["n_gpus"] == 1 and rec["ranks_seen"] == 1 and rec["backend"] == "nccl" and "od_allgather_compact" in rec["collective"], rec
     assert "all-gather" in rec["config"]["parallelism"] and rec["value"] > 0
     d = os.path.join(ROOT, "gpurun_out")
     os.makedirs(d, exist_ok=True)

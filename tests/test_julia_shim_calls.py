@@ -33,9 +33,9 @@ def test_every_ccall_of_the_shim_names_an_exported_symbol_with_matching_arity(em
             # ... and the same class of C type in every position (a Cint where the header says long reads garbage on x86-64)
             import ctypes as C
             def jclass(t):
-                return "ptr" if t.startswith(("Ptr", "Ref", "Cstring")) else {"Cint": "int", "Clong": "long", "Cdouble": "double"}[t]
+                return "ptr" if t.startswith(("Ptr", "Ref", "Cstring")) else {"Cint": "int", "Clong": "long", "Cdouble": "double", "Csize_t": "size"}[t]
             def cclass(t):
-                return {C.c_int: "int", C.c_long: "long", C.c_double: "double"}.get(t, "ptr")
+                return {C.c_int: "int", C.c_long: "long", C.c_double: "double", C.c_size_t: "size"}.get(t, "ptr")
             assert [jclass(a) for a in jargs] == [cclass(t) for t in _lib.SIGNATURES[sym][1]], sym
             assert jclass(ret) == cclass(_lib.SIGNATURES[sym][0]), sym
 
@@ -148,6 +148,59 @@ def _rocket_sequence(oracle, emu_lib, device):
     assert np.hypot(up[0], up[1]) <= up[2] + 2e-2            # examples/rocket.jl:151
     assert emu_lib.cdll.od_destroy(hd) == 0
 
+
+
+def _communicator_sequence(lib, device):
+    """Communicator / allgather_compact! of the shim: od_version check of __init__, od_comm_unique_id (128 bytes), od_comm_create with the
+    handle, od_comm_info with a NULL device pointer, od_set_layout(1) + od_rollout_compact (od_rollout_compact!: Julia n x K matrices are
+    batch-major), od_allgather_compact, od_comm_allgather with a byte count, od_comm_destroy -- one rank; block 0 of the gathered arrays
+    is the rollout's output bit for bit (the layout is the handle's: the gather ships the arrays as they stand)"""
+    import bench
+    import parity_checks as P
+    from optimization_dynamics_amd import _lib
+    assert lib.cdll.od_version() == _lib.ABI_VERSION == 101
+    src = open(os.path.join(ROOT, "julia", "OptimizationDynamicsMI355X.jl")).read()
+    assert "const ABI_VERSION = %d" % _lib.ABI_VERSION in src and "zeros(UInt8, %d)" % _lib.COMM_ID_BYTES in src
+    B, T = 6, 5
+    im = P.make_im("hopper", lib, device)
+    uid = (C.c_ubyte * 128)()
+    assert lib.cdll.od_comm_unique_id(uid) == 0
+    hd = C.c_void_p()
+    assert lib.cdll.od_comm_create(im._h, uid, 0, 1, C.byref(hd)) == 0
+    w, r = C.c_int(-1), C.c_int(-1)
+    assert lib.cdll.od_comm_info(hd, C.byref(w), C.byref(r), None) == 0 and (w.value, r.value) == (1, 0)
+    x1, U = bench.workload_slice(0, B, B, T)
+    dev = torch.device(device)
+    x1j = torch.tensor(np.ascontiguousarray(x1.T), device=dev)                      # Julia 8 x B column-major == B x 8 row-major
+    Uj = torch.tensor(np.ascontiguousarray(U.reshape(2, T * B).T), device=dev)
+    X = torch.zeros((T + 1) * B, 8, dtype=torch.float64, device=dev); G = torch.zeros(T * B, 40, dtype=torch.float64, device=dev)
+    Xa, Ga = torch.zeros_like(X), torch.zeros_like(G)
+    assert lib.cdll.od_set_layout(im._h, 1) == 0
+    assert lib.cdll.od_rollout_compact(im._h, B, T, x1j.data_ptr(), Uj.data_ptr(), X.data_ptr(), G.data_ptr(), None, None) == 0
+    assert lib.cdll.od_allgather_compact(im._h, hd, B, T, X.data_ptr(), G.data_ptr(), Xa.data_ptr(), Ga.data_ptr()) == 0
+    k = torch.arange(11, dtype=torch.float64, device=dev); ka = torch.zeros_like(k)
+    assert lib.cdll.od_comm_allgather(im._h, hd, k.data_ptr(), ka.data_ptr(), C.c_size_t(88)) == 0
+    assert lib.cdll.od_synchronize(im._h) == 0
+    assert torch.equal(Xa, X) and torch.equal(Ga, G) and torch.equal(ka, k) and X.abs().sum().item() > 0
+    # the same numbers as the batch-minor rollout of the Python mirror
+    assert lib.cdll.od_set_layout(im._h, 0) == 0
+    Xm, Gm, st, it, out = im.rollout_compact(torch.tensor(x1, device=dev), torch.tensor(U, device=dev))
+    assert torch.equal(X.T.reshape(8, T + 1, B), Xm)
+    assert lib.cdll.od_comm_destroy(hd) == 0
+
+
+def test_communicator_sequence(emu_lib):
+    import glob
+    try:
+        _communicator_sequence(emu_lib, "cpu")
+    finally:
+        for f in glob.glob("/dev/shm/odemu_%d_*" % os.getpid()):
+            os.remove(f)
+
+
+@pytest.mark.gpu
+def test_communicator_sequence_gpu(gpu_lib):
+    _communicator_sequence(gpu_lib, "cuda:0")
 
 
 # the three call sequences on the host build of the product sources (CPU tier) and on the shipped HIP library (-m gpu): the shim's
