@@ -296,7 +296,10 @@ int od_ilqr_set_constraints(od_ilqr s, int ns, int ns_ineq, const double* Cs, co
  * Lagrangian like the rows of od_ilqr_set_constraints, whose stage rows keep applying to (slot state, control) at every knot.  The
  * iteration is the one described above -- Riccati pass on the model of the reference's formulation at its dimensions (2 n states,
  * m + n controls), candidates rolled out from their own theta + alpha dtheta by the kernels of the path -- with no host
- * synchronisation.  Host pointers; call before od_ilqr_init; NULL removes the stage. */
+ * synchronisation.  Host pointers; call before od_ilqr_init; NULL removes the stage.
+ * NOT combinable with goal components (od_ilqr_set_objective, ngoal > 0) or terminal rows of od_ilqr_set_constraints (nt > 0): the
+ * stage's terminal model consists of QT and its own coupled rows, so either call answers OD_ERR_UNSUPPORTED while the other kind is
+ * in force (state such conditions as coupled rows with Ct_theta = 0); at most 64 constraint parameters. */
 typedef struct {
   int constraint;            /* id of a generated constraint function on theta (od_constraint_id), -1: none; all rows equalities */
   int n_p; const double* p;  /* its parameters (od_constraint_dims) */

@@ -99,6 +99,8 @@ def emit(c) -> str:
     nc = len(rows)
     if nc < 1 or nc > 16 or c.nx > 16:
         raise ValueError("1..16 rows on at most 16 variables (OD_IL_MAXCON, OD_IL_N)")
+    if c.np < 0 or c.np > 64:
+        raise ValueError("at most 64 parameters (the solver's constant block, od_ilqr_set_parameter_stage)")
     J = sp.Matrix(rows).jacobian(sp.Matrix(x))
     nzj = [(i, j) for j in range(c.nx) for i in range(nc) if J[i, j] != 0]
     pr = _DevicePrinter()

@@ -1187,7 +1187,7 @@ struct od_handle_s {
   size_t hstage_elems;
   std::vector<od_ilqr_s*> solvers;   // live od_ilqr solvers made from this handle (od_destroy releases what they hold)
 };
-static void il_detach_all(od_handle_s* h);      // od_ilqr_solver.inc
+static void il_detach_all(od_handle_s* h, bool device_ok);      // od_ilqr_solver.inc
 
 namespace {
 
@@ -1542,13 +1542,20 @@ int od_create(int model, int dtype, const od_options* opts, double dt, od_handle
 
 int od_destroy(od_handle h) {
   if (!h) return OD_OK;
-  OD_ON_DEVICE(h);
-  il_detach_all(h);
-  if (h->stage) (void)hipFree(h->stage);
-  if (h->hstage) (void)hipHostFree(h->hstage);
-  if (h->work) (void)hipFree(h->work);
+  // best effort (called from finalisers that ignore the return code): if the handle's device cannot be made current no HIP call is made on
+  // another one, but the host objects go and the live solvers are detached all the same
+  int rc = OD_OK;
+  OnDevice g(h->device);
+  const bool dev_ok = g.err == hipSuccess;
+  if (!dev_ok) rc = fail(OD_ERR_HIP, std::string("od_destroy: switching to the handle's device: ") + hipGetErrorString(g.err) + " (device memory not released)");
+  il_detach_all(h, dev_ok);
+  if (dev_ok) {
+    if (h->stage) (void)hipFree(h->stage);
+    if (h->hstage) (void)hipHostFree(h->hstage);
+    if (h->work) (void)hipFree(h->work);
+  }
   delete h;
-  return OD_OK;
+  return rc;
 }
 
 int od_get_device(od_handle h, int* device) {

@@ -383,13 +383,16 @@ class ILQR:
     def solve_stepwise(self, *args, **kw):
         """`_solve_stepwise` with the thrust-cone projection's stall exit switched on for the handle while it runs, as the device-resident
         solver does for its own launches (od_ilqr_options.proj_stall_exit; the handle's default is off, like the reference)"""
+        if getattr(self.obj, "parameter_stage", None) is not None:
+            raise NotImplementedError("solve_stepwise has no parameter stage (od_ilqr_set_parameter_stage): its checker is oracle/ilqr_np.py::solve_stages")
         info = getattr(self.im, "info", None)
         if info is not None and hasattr(info, "set_projection_stall_exit"):
+            before = getattr(info, "projection_stall_exit", False)       # (a caller's own setting survives this call)
             info.set_projection_stall_exit(kw.pop("proj_stall_exit", True))
             try:
                 return self._solve_stepwise(*args, **kw)
             finally:
-                info.set_projection_stall_exit(False)
+                info.set_projection_stall_exit(before)
         kw.pop("proj_stall_exit", None)
         return self._solve_stepwise(*args, **kw)
 

@@ -40,6 +40,7 @@ class RocketInfo:
         with _lib.on_device(self.device):
             self.lib.check(self.lib.cdll.od_create(self.lib.model_id("rocket_dynamics"), od_dtype, C.byref(o), self.h, C.byref(hd)))
         self._h = hd
+        self.projection_stall_exit = False          # od_create's default (the reference runs every iteration)
         self.lib.check(self.lib.cdll.od_set_u_max(self._h, self.u_max))
 
     def __del__(self):
@@ -57,6 +58,7 @@ class RocketInfo:
     def set_projection_stall_exit(self, on):
         """od_set_projection_stall_exit: off (the default) runs every iteration of a stalled thrust-cone projection like the reference"""
         self.lib.check(self.lib.cdll.od_set_projection_stall_exit(self._h, 1 if on else 0))
+        self.projection_stall_exit = bool(on)
 
     def project_full(self, U, grads=True):
         """od_soc_project_full: U (3, B) -> z (10, B) whole solution of the projection's solve, duproj (3, 3, B) or None, status, iterations"""

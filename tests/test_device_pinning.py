@@ -98,6 +98,63 @@ def test_destroying_the_handle_before_its_solver_is_safe(emu_lib):
     assert cd.od_ilqr_destroy(s2) == 0
 
 
+def test_destroy_is_best_effort_when_the_device_guard_fails(emu_lib, two_devices):
+    """od_destroy / od_ilqr_destroy run from finalisers that ignore the return code: if switching to the handle's device fails (the
+    device is gone) they report the error but the host objects go and the solver leaves the handle's list -- round 5 returned early,
+    leaked everything and left the solver in h->solvers for a second release.  Emulated: a handle on device 1, then one device visible."""
+    emu = two_devices
+    for order in ("solver_first", "handle_first"):
+        emu.od_emu_set_device_count(2)
+        emu.od_emu_set_device(1)
+        im = P.make_im("cartpole_friction", emu_lib, "cpu")
+        dev = C.c_int(-1)
+        assert emu_lib.cdll.od_get_device(im._h, C.byref(dev)) == 0 and dev.value == 1
+        al = (C.c_double * 2)(1.0, 0.5)
+        s = C.c_void_p()
+        assert emu_lib.cdll.od_ilqr_create(im._h, 4, 3, 2, al, None, C.byref(s)) == 0
+        emu.od_emu_set_device(0)
+        emu.od_emu_set_device_count(1)                       # device 1 is gone: hipSetDevice(1) fails
+        h, im._h = im._h, None                               # (ours to destroy now)
+        if order == "solver_first":
+            assert emu_lib.cdll.od_ilqr_destroy(s) == -3 and b"device" in emu_lib.cdll.od_last_error()
+            assert emu_lib.cdll.od_destroy(h) == -3
+        else:
+            assert emu_lib.cdll.od_destroy(h) == -3 and b"device" in emu_lib.cdll.od_last_error()
+            assert emu_lib.cdll.od_ilqr_init(s, None, None) == -1        # detached: answers, does not touch freed memory
+            assert emu_lib.cdll.od_ilqr_destroy(s) == 0
+
+
+def test_parameter_stage_excludes_goals_and_plain_terminal_rows(emu_lib):
+    """with a parameter stage the Riccati pass starts from the stage's own terminal model; goal components and terminal
+    rows of od_ilqr_set_constraints would be charged by the merit only -- refused in either order of the calls"""
+    from optimization_dynamics_amd import _lib
+    im = P.make_im("hopper", emu_lib, "cpu")
+    al = (C.c_double * 2)(1.0, 0.5)
+    n, m = 8, 2
+    I8 = (C.c_double * 64)(*np.eye(8).ravel()); I2 = (C.c_double * 4)(*np.eye(2).ravel()); xr = (C.c_double * 8)()
+    w = (C.c_double * 8)(*([0.1] * 8))
+    gi = (C.c_int * 1)(0); gv = (C.c_double * 1)(1.0)
+    Ct = (C.c_double * 8)(*([1.0] + [0.0] * 7)); dt = (C.c_double * 1)(0.5)
+    ps = _lib.IlqrParameterStage(constraint=-1, n_p=0, p=None, w_theta=w, cost_const=0.0, nt=0, nt_ineq=0, Ct_x=None, Ct_theta=None, dt=None)
+    cd = emu_lib.cdll
+    # goals first, then the stage
+    s = C.c_void_p(); assert cd.od_ilqr_create(im._h, 2, 3, 2, al, None, C.byref(s)) == 0
+    assert cd.od_ilqr_set_objective(s, I8, I2, I8, xr, 1, gi, gv) == 0
+    assert cd.od_ilqr_set_parameter_stage(s, C.byref(ps)) == -2 and b"parameter stage" in cd.od_last_error()
+    assert cd.od_ilqr_set_objective(s, I8, I2, I8, xr, 0, None, None) == 0
+    assert cd.od_ilqr_set_constraints(s, 0, 0, None, None, None, 1, 0, Ct, dt) == 0
+    assert cd.od_ilqr_set_parameter_stage(s, C.byref(ps)) == -2
+    assert cd.od_ilqr_set_constraints(s, 0, 0, None, None, None, 0, 0, None, None) == 0
+    assert cd.od_ilqr_set_parameter_stage(s, C.byref(ps)) == 0
+    # the stage first, then goals / terminal rows
+    assert cd.od_ilqr_set_objective(s, I8, I2, I8, xr, 1, gi, gv) == -2
+    assert cd.od_ilqr_set_constraints(s, 0, 0, None, None, None, 1, 0, Ct, dt) == -2
+    assert cd.od_ilqr_set_objective(s, I8, I2, I8, xr, 0, None, None) == 0          # without goals: fine
+    assert cd.od_ilqr_set_parameter_stage(s, None) == 0                              # stage removed: goals are back
+    assert cd.od_ilqr_set_objective(s, I8, I2, I8, xr, 1, gi, gv) == 0
+    assert cd.od_ilqr_destroy(s) == 0
+
+
 def test_constraints_can_be_replaced_without_growth(emu_lib):
     """od_ilqr_set_constraints allocates its buffers once: replacing the constraints many times reuses them, and what is in force
     after each call is what that call passed"""
