@@ -142,6 +142,21 @@ def config3(dev, cpu=True):
         dt = time.time() - t0
         out["cpu_baseline"] = dict(value=k * (N + 1) / dt, unit="solves/s", cores=1, kind="port",
                                    sample="gradient! on the first %d of the %d knots (%d solves + %d Newton least-squares fits), %.1f s, one thread; CPU restatement" % (k, K, k * (N + 1), k, dt))
+        # ... and on all host cores (single thread AND all cores): the knots are independent, one gradient! per thread (the C
+        # oracle runs outside the interpreter lock)
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        cores = os.cpu_count() or 1
+        sims = [P.make_sim(O, "planar_push") for _ in range(cores)]
+        def one(i):
+            O.gradient_bundle(sims[i % cores], eta, X[:5, i % K], X[5:, i % K], U[:, i % K])
+        t0 = time.time(); done = 0
+        with ThreadPoolExecutor(cores) as ex:
+            while time.time() - t0 < 6.0:
+                list(ex.map(one, range(done, done + cores))); done += cores
+        dta = time.time() - t0
+        out["cpu_baseline"]["all_cores"] = dict(value=done * (N + 1) / dta, unit="solves/s", cores=cores, kind="port",
+                                                 sample="gradient! on %d knots (cycling through the %d), one knot per thread, %.1f s" % (done, K, dta))
     return out
 
 
@@ -268,6 +283,20 @@ def config5(dev, cpu=True):
         dt = time.time() - t0
         out["cpu_baseline"] = dict(value=k / dt, unit="projected rocket steps (f+fx+fu)/s", cores=1, kind="port",
                                    sample="%d calls of f_rocket_proj + fx + fu (projection solve, dynamics solve, both implicit gradients) at the example's initial state, %.1f s, one thread; CPU restatement" % (k, dt))
+        # ... and on all host cores: the oracle's batched entry points (OpenMP over the knots) -- projection with its gradient, then the
+        # dynamics step with its gradient at the projected control, the work of f / fx / fu_rocket_proj on independent knots
+        import os
+        cores = os.cpu_count() or 1
+        nb = 4096
+        Xb = np.repeat(x1[:, :1], nb, axis=1) + 1e-3 * rng.normal(size=(12, nb))
+        Ub = U0[:, rng.integers(0, 60, nb), 0] + 1e-3 * rng.normal(size=(3, nb))
+        t0 = time.time(); done = 0
+        while time.time() - t0 < 6.0:
+            Zp, _, _, _ = O.soc_projection_batch(12.5, Ub, True)
+            O.rocket_batch(0.05, Xb, Zp[:3], True); done += nb
+        dta = time.time() - t0
+        out["cpu_baseline"]["all_cores"] = dict(value=done / dta, unit="projected rocket steps (f+fx+fu)/s", cores=cores, kind="port",
+                                                 sample="%d knots in batches of %d (soc_projection + gradient, then the dynamics step + gradient), OpenMP over the knots, %.1f s" % (done, nb, dta))
     return out
 
 

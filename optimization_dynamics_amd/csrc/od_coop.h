@@ -766,25 +766,6 @@ OD_HD int coop_ip_step(const CoopLanes<CM, RO>& L, const Opts<double>& o, const 
     const bool last = it >= o.max_iter;
     if (!grad_done && ((req && k_vio < o.kappa_grad) || last)) {
       defer(z, od_max(reg_prev, o.kappa_grad * o.gamma_reg));
-#ifdef OD_EXPERIMENT_FUSED_GRAD_COST
-      // MEASUREMENT ONLY (tools/build_variants.sh; never in the shipped library): what a gradient fused into the cooperative
-      // row would put on the trajectory's critical path -- one pivoted factorisation at the gradient iterate and 2nq + nu
-      // cooperative back-solves (a stand-in right-hand side; the 319-operation rtheta evaluation is not even counted).
-      {
-        CoopFact<CM, RO> fg;
-        if (!coop_eval_factor<CM, true, RO>(L, z, th, pre, tr, od_max(reg_prev, o.kappa_grad * o.gamma_reg), fg)) status &= ~OD_ST_FACTOR_OK;
-        CoopVec<NQ, V> xg;
-        CoopRes<NQ, V> rg = r;
-        double accg = 0.0;
-        for (int c = 0; c < 2 * NQ + CM::M::NU; ++c) {
-          rg.rd[c % NQ] += 1.0;
-          coop_solve<CM, true, RO>(L, fg, z, rg, xg);
-#pragma unroll
-          for (int k = 0; k < NQ; ++k) accg += xg.q[k];
-        }
-        if (accg == 1.2345e300) status |= 64;          // keeps the work alive
-      }
-#endif
       grad_done = true;
       iters[1] = it;
       if (!last) status |= OD_ST_GRAD_OK;
@@ -888,152 +869,6 @@ template <class CM, class RO> OD_HD void coop_unit_step_state(const StepArgs<dou
   coop_knot_state<CM, RO>(L, a, b, x, u, q3);
 }
 
-#ifdef OD_EXPERIMENT_ROW_DECOUPLING
-// MEASUREMENT ONLY (tools/build_variants.sh; never in the shipped library): the rollout with PER-ROW PROGRESS -- every row of
-// the wavefront advances to its next knot on its own instead of waiting for the slowest of the four at every knot (DESIGN.md
-// 3.5).  One loop trip = [knot set-up for the rows that start a knot | factorisation, directions, step length for the rows in
-// an iteration] + ONE residual evaluation site shared by all rows (the initial residual of a new knot, or a line-search
-// trial) + the convergence bookkeeping.  Same functions, same arithmetic per knot as coop_ip_step / coop_iteration (with the
-// sequential line search): results are bit-identical, only the order in which the rows' work is interleaved changes.
-template <class CM, class RO> OD_HD void coop_unit_rollout_state(const RolloutArgs<double>& ra, long b) {
-  using M = typename CM::M;
-  using V = typename RO::V;
-  using Vec = CoopVec<CM::NQ, V>;
-  using Res = CoopRes<CM::NQ, V>;
-  constexpr int nq = M::NQ, n = 2 * M::NQ, NQ = CM::NQ;
-  constexpr bool CONES = (CM::NC + CM::NK) > 0;
-  constexpr bool PIV = !M::STATIC_TAIL;
-  const StepArgs<double>& a = ra.s;
-  const Opts<double>& o = a.opts;
-  double x[n], u[M::NU > 0 ? M::NU : 1];
-#pragma unroll
-  for (int i = 0; i < n; ++i) x[i] = a.x.at(i, b);
-  if (ra.x0.ok() && RO::first_lane()) {
-#pragma unroll
-    for (int i = 0; i < n; ++i) ra.x0.at(i, b) = x[i];
-  }
-  CoopLanes<CM, RO> L0;
-  L0.init();
-  CoopLanes<CM, RO> L = L0;
-  double th[M::NTH], pre[M::NPRE], tr[M::NTR], qs[NQ];
-  Vec z, D;
-  Res r;
-  StepPre<RO> sp;
-  double r_vio = 0.0, k_vio = 0.0, reg_prev = 0.0, alpha = 0.0;
-  int it = 0, ls = 0, status = 0, it0 = 0, it1 = 0, t = 0;
-  bool is_new = true, need_dir = false, eval_done = false, grad_done = false;
-#pragma unroll
-  for (int k = 0; k < NQ; ++k) { D.q[k] = 0.0; qs[k] = 0.0; }
-  D.P0 = D.P1 = D.D0 = D.D1 = V(0.0);
-  while (t < ra.Tn) {
-    const long k = (long)t * a.B + b;
-    if (is_new) {
-#pragma unroll
-      for (int i = 0; i < M::NU; ++i) u[i] = a.u.at(i, k);
-      double z0[M::NZ];
-      mech_setup<M>(x, x + nq, u, a.fric, a.h, th, z0);
-      L = L0;
-      L.set_theta(th);
-#pragma unroll
-      for (int i = 0; i < nq; ++i) z.q[i] = z0[CM::ZQ[i]];
-      z.P0 = RO::lane_table(CM::ZI_P0); z.P1 = RO::lane_table(CM::ZI_P1);
-      z.D0 = RO::lane_table(CM::ZI_D0); z.D1 = RO::lane_table(CM::ZI_D1);
-      M::eval_pre(th, pre);
-      it = 0; it0 = it1 = 0; eval_done = false; grad_done = a.want_grad == 0; status = OD_ST_FACTOR_OK; reg_prev = 0.0;
-    } else if (need_dir) {
-      CoopFact<CM, RO> f;
-      const double reg = (k_vio < o.kappa_reg) ? k_vio * o.gamma_reg : 0.0;
-      reg_prev = reg;
-      if (!coop_eval_factor<CM, PIV, RO>(L, z, th, pre, tr, reg, f)) status &= ~OD_ST_FACTOR_OK;
-      coop_solve<CM, PIV, RO>(L, f, z, r, D);
-      sp = coop_step_pre<CM, RO>(L, z);
-      if constexpr (CONES) {
-        const double aaff = coop_step_length<CM, RO>(L, sp, D, 1.0, 1.0);
-        double kap = coop_centering<CM, RO>(L, z, D, aaff);
-        kap = od_fmax(kap, o.kappa_eval * o.undercut_inv);
-        Res rk = r;
-        rk.rA = r.rA - kap + (D.P0 * D.D0 + D.P1 * D.D1);
-        rk.rB = r.rB + (D.P0 * D.D1 + D.P1 * D.D0);
-        coop_solve<CM, PIV, RO>(L, f, z, rk, D);
-      }
-      const double vio = RO::vmax(r_vio, k_vio);
-      const double tau = 1.0 - od_fmin(o.eps_min, vio * vio);
-      alpha = coop_step_length<CM, RO>(L, sp, D, tau, od_fmin(tau, 0.99));
-      ls = 0;
-    }
-    // the one residual site: r(z0) of a new knot, or a line-search trial
-    Vec zc;
-    Res rc;
-    double r_c, k_c;
-    const double ae = is_new ? 0.0 : alpha;
-    if (is_new) {
-      zc = z;
-    } else {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) zc.q[q] = z.q[q] - ae * D.q[q];
-      zc.P0 = z.P0 - ae * D.P0; zc.P1 = z.P1 - ae * D.P1;
-      zc.D0 = z.D0 - ae * D.D0; zc.D1 = z.D1 - ae * D.D1;
-    }
-    coop_eval_r<CM, RO>(L, zc, th, pre, tr, rc);
-    coop_viol<CM, RO>(L, rc, r_c, k_c);
-    if (is_new) {
-      r = rc; r_vio = r_c; k_vio = k_c;
-      is_new = false;
-    } else {
-      const bool accept = (r_c <= r_vio || k_c <= k_vio) || (ls + 1 >= o.max_ls);
-      if (!accept) {
-        alpha *= 0.5;
-        ++ls;
-        need_dir = false;
-        continue;
-      }
-      z = zc; r = rc; r_vio = r_c; k_vio = k_c;
-      ++it;
-    }
-    // the tests at the top of coop_ip_step's loop
-    const bool req = r_vio < o.r_tol;
-    const bool last = it >= o.max_iter;
-    if (!grad_done && ((req && k_vio < o.kappa_grad) || last)) {
-      CoopDefer<CM, RO> defer{a.zg, k, L0.zg_idx};
-      defer(z, od_max(reg_prev, o.kappa_grad * o.gamma_reg));
-      grad_done = true;
-      it1 = it;
-      if (!last) status |= OD_ST_GRAD_OK;
-    }
-    if (!eval_done && ((req && k_vio < o.kappa_eval) || last)) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) qs[q] = z.q[q];
-      eval_done = true;
-      it0 = it;
-      if (!last) status |= OD_ST_EVAL_OK;
-    }
-    if (eval_done && grad_done) {
-      if (RO::first_lane()) {
-        if (a.d.ok()) {
-          auto c = a.d.cursor(k);
-#pragma unroll
-          for (int i = 0; i < nq; ++i) c.put(x[nq + i]);
-#pragma unroll
-          for (int i = 0; i < nq; ++i) c.put(qs[i]);
-        }
-        if (a.q3.ok()) {
-          auto c = a.q3.cursor(k);
-#pragma unroll
-          for (int i = 0; i < nq; ++i) c.put(qs[i]);
-        }
-        if (a.status.ok()) a.status.at(0, k) = status;
-        if (a.iters.ok()) { auto c = a.iters.cursor(k); c.put(it0); c.put(it1); }
-      }
-#pragma unroll
-      for (int i = 0; i < nq; ++i) { x[i] = x[nq + i]; x[nq + i] = qs[i]; }
-      ++t;
-      is_new = true;
-    } else {
-      need_dir = true;
-    }
-  }
-}
-#else
 template <class CM, class RO> OD_HD void coop_unit_rollout_state(const RolloutArgs<double>& ra, long b) {
   using M = typename CM::M;
   constexpr int nq = M::NQ, n = 2 * M::NQ;
@@ -1066,7 +901,6 @@ template <class CM, class RO> OD_HD void coop_unit_rollout_state(const RolloutAr
   }
 }
 
-#endif
 
 // closed-loop rollout = forward pass of iLQR (od_units.h::unit_rollout_policy): candidate p = a*Bnom + b follows the
 // nominal trajectory b with step size alphas[a], u_t = ubar_t + alpha k_t + K_t (x_t - xbar_t); one candidate per row

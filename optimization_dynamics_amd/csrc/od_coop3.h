@@ -748,8 +748,8 @@ OD_HD bool c3_iteration(const C3Lanes<CM, RO>& L, const Opts<double>& o, const d
   const double tau = 1.0 - od_fmin(o.eps_min, vio * vio);
   double alpha = c3_step_length<CM, RO>(L, sp, z, D, tau, od_fmin(tau, 0.99));
   // backtracking until either violation does not increase (od_solver.h::line_search), every trial in turn.  The lane-parallel
-  // rounds of od_coop.h::coop_iteration exist here too (OD_EXPERIMENT_C3_PARALLEL_LS: the 8 lanes of the group each try a
-  // step size, c3_trials_lanes): bit-identical results (profiles/r3_hash_c3_parallel_ls.json), planar push unchanged,
+  // rounds of od_coop.h::coop_iteration exist as a measurement variant (tools/variants/c3_parallel_ls.patch: the 8 lanes of the group each
+  // try a step size, c3_trials_lanes): bit-identical results (profiles/r3_hash_c3_parallel_ls.json), planar push unchanged,
   // hopper rollouts 8 % (8192) to 48 % (>= 16 384, spills at two wavefronts per SIMD) slower -- profiles/r3_c3_parallel_ls_ab.json
   Vec zc;                                    // (set by the first trial: max_ls >= 1 is enforced at the API)
   Res rc;
@@ -763,37 +763,13 @@ OD_HD bool c3_iteration(const C3Lanes<CM, RO>& L, const Opts<double>& o, const d
     c3_viol<CM, RO>(L, rc, r_c, k_c);
     return r_c <= r_vio || k_c <= k_vio;
   };
-#ifdef OD_EXPERIMENT_C3_PARALLEL_LS          // (measurement variant, tools/build_variants.sh)
-  const int nseq = ls_hint >= 2 ? 0 : (o.max_ls < 2 ? o.max_ls : 2);
-#else
   const int nseq = o.max_ls;                 // shipped: every trial in turn (the lane-parallel rounds measured slower here)
-#endif
   bool done = false;
   int ls = 0;
   for (; ls < nseq; ++ls) {
     if (trial(alpha)) { done = true; break; }
     if (ls + 1 < o.max_ls) alpha *= 0.5;
   }
-#ifdef OD_EXPERIMENT_C3_PARALLEL_LS
-  if (!done && ls < o.max_ls) {
-    bool found = false;
-    for (int j0 = ls; j0 < o.max_ls && !found; j0 += 8) {
-      const typename RO::B acc = c3_trials_lanes<CM, RO>(L, th, pre, z, D, RO::lane_ldexp(alpha), r_vio, k_vio) && RO::lane_below(o.max_ls - j0);
-      const unsigned m = RO::grp_ballot(acc);
-      if (m != 0) {
-        alpha = od_ldexp(alpha, -__builtin_ctz(m));                      // first accepted trial of the round
-        found = true;
-        ls = j0 + __builtin_ctz(m);
-      } else {
-        ls = o.max_ls - 1;
-        const int left = o.max_ls - 1 - j0;                              // trials after j0: move on by 8, or to the last
-        alpha = od_ldexp(alpha, -(left < 8 ? left : 8));
-        if (left < 8) break;                                             // alpha is now the last trial's step
-      }
-    }
-    trial(alpha);                                                        // the group lands on the chosen trial
-  }
-#endif
   // (a zero step whose trial reproduced both violations bit for bit: every further iteration would repeat this one)
   const bool fixed_point = (alpha == 0.0) && done && ls == 0 && r_c == r_vio && k_c == k_vio;
   ls_hint = ls;

@@ -253,9 +253,6 @@ template <class T, int N> OD_HD bool od_lu_factor(T* A, int* piv) {
     // solves stopped converging depending on unrelated source details (a printf made them converge).
     bool exchange = true;
     if constexpr (N <= OD_LU_BRANCHY_MAX) exchange = od_any_lane(p != k);
-#ifdef OD_LU_EXEC_MASKED_EXCHANGE   // experiment only (tools/pp_hazard_check.py): per-lane branch instead of the wave-uniform one
-    exchange = (p != k);
-#endif
     if (exchange) {
 #pragma unroll
       for (int i = k + 1; i < N; ++i) {
@@ -272,12 +269,8 @@ template <class T, int N> OD_HD bool od_lu_factor(T* A, int* piv) {
     // 1 once the violation is below 1e-8) makes the system singular; in the small tails its unknown is
     // dropped (x_k = 0) so that the outputs stay finite; the caller reports the knot through FACTOR_OK
     T inv;
-#ifdef OD_LU_NO_PIVOT_GUARD          // experiment only
-    inv = od_rcp(A[k + N * k]);
-#else
     if constexpr (N > OD_LU_BRANCHY_MAX) inv = od_rcp(A[k + N * k]);
     else inv = best > T(0) ? od_rcp(A[k + N * k]) : T(0);
-#endif
     A[k + N * k] = inv;                       // the diagonal holds 1/u_kk
 #pragma unroll
     for (int i = k + 1; i < N; ++i) A[i + N * k] *= inv;

@@ -35,12 +35,7 @@ hipError_t launch_soc_project32(const SocProjectArgs<float>& a, int ppw, hipStre
   return hipGetLastError();
 }
 
-#ifdef OD_EXPERIMENT_ROLLOUT_OCC     // MEASUREMENT ONLY (tools/build_variants.sh): the rollout kernels held to OD_EXPERIMENT_ROLLOUT_OCC wavefronts per SIMD
-#define OD_ROLLOUT_ATTR __attribute__((amdgpu_waves_per_eu(OD_EXPERIMENT_ROLLOUT_OCC, OD_EXPERIMENT_ROLLOUT_OCC)))
-#else
-#define OD_ROLLOUT_ATTR
-#endif
-template <class T> __global__ __launch_bounds__(OD_BLOCK) OD_ROLLOUT_ATTR void k_rocket_rollout(RocketRolloutArgs<T> a, LaneMap lm) {
+template <class T> __global__ __launch_bounds__(OD_BLOCK) void k_rocket_rollout(RocketRolloutArgs<T> a, LaneMap lm) {
   if (a.a.skip && *a.a.skip) return;
   const long p = lm.problem(blockIdx.x, threadIdx.x);
   if (lm.active(threadIdx.x) && p < a.a.B && (!a.a.live || a.a.live[p % a.a.live_mod])) unit_rocket_rollout<Model_rocket_dynamics, Model_rocket_projection_direct, T>(a, p);

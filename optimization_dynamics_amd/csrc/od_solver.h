@@ -513,9 +513,6 @@ OD_HD int ip_step_grad(const Opts<T>& o, const T* th, T* z, bool want_state, boo
       T alpha;
       ip_iteration<M>(o, th, pre, tr, z, r, r_vio, k_vio, reg_prev, status, it, f, &alpha);
       nstall = (alpha < T(sizeof(T) == 4 ? M::STALL_ALPHA_F32 : M::STALL_ALPHA)) ? nstall + 1 : 0;
-#ifdef OD_EXPERIMENT_ITERS_IN_STATUS   // MEASUREMENT ONLY: the trips the loop really made (a stall exit reports max_iter)
-      ++iters[1];
-#endif
       if (stall_exit && nstall >= M::STALL_ITERS && it + 1 < o.max_iter) it = o.max_iter - 1;
     } else {
       ip_iteration<M>(o, th, pre, tr, z, r, r_vio, k_vio, reg_prev, status, it, f);

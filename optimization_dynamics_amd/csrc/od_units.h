@@ -630,9 +630,6 @@ OD_HD int soc_project_solve(const RocketArgs<T>& a, const T* thp, T* zp, bool wa
 template <class MD, class MP, class T> OD_HD void rocket_knot_state(const RocketArgs<T>& a, long b, const T* x, T* u, T* y, int* ok_and = nullptr) {
   int st = 0;
   NoGradSink<T> ns;
-#ifdef OD_EXPERIMENT_ITERS_IN_STATUS
-  int itp_[2] = {0, 0};
-#endif
   if (a.project) {
     T zp[MP::NZ], thp[MP::NTH];
 #pragma unroll
@@ -640,9 +637,6 @@ template <class MD, class MP, class T> OD_HD void rocket_knot_state(const Rocket
     thp[0] = u[0]; thp[1] = u[1]; thp[2] = u[2]; thp[3] = a.u_max;
     int itp[2];
     const int sp_ = soc_project_solve<MP, false>(a, thp, zp, false, ns, itp);
-#ifdef OD_EXPERIMENT_ITERS_IN_STATUS
-    itp_[0] = itp[1];
-#endif
     st |= (sp_ & 1) << 4;
     u[0] = zp[0]; u[1] = zp[1]; u[2] = zp[2];
     if (a.uproj.ok()) { a.uproj.at(0, b) = u[0]; a.uproj.at(1, b) = u[1]; a.uproj.at(2, b) = u[2]; }
@@ -658,11 +652,7 @@ template <class MD, class MP, class T> OD_HD void rocket_knot_state(const Rocket
     if (a.polish64) rocket_refine64<MD>(x, u, a.h64, th, y, fd, it[0] > 0);
   }
   st |= (sd & (OD_ST_EVAL_OK | OD_ST_FACTOR_OK));
-#ifdef OD_EXPERIMENT_ITERS_IN_STATUS   // MEASUREMENT ONLY (tools/diag_config5_rollout.py): iteration counts of the two solves in the status word
-  if (a.status.ok()) a.status.at(0, b) = st | ((a.project ? itp_[0] : 0) << 8) | (it[0] << 16);
-#else
   if (a.status.ok()) a.status.at(0, b) = st;
-#endif
   if (ok_and) *ok_and &= st;                  // (bit 0: the dynamics solve converged)
 }
 

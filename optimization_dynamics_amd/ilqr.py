@@ -384,7 +384,7 @@ class ILQR:
         """`_solve_stepwise` with the thrust-cone projection's stall exit switched on for the handle while it runs, as the device-resident
         solver does for its own launches (od_ilqr_options.proj_stall_exit; the handle's default is off, like the reference)"""
         if getattr(self.obj, "parameter_stage", None) is not None:
-            raise NotImplementedError("solve_stepwise has no parameter stage (od_ilqr_set_parameter_stage): its checker is oracle/ilqr_np.py::solve_stages")
+            raise NotImplementedError("solve_stepwise has no parameter stage (od_ilqr_set_parameter_stage): the device solver with a parameter stage is checked by the numpy restatement under tests (solve_stages)")
         info = getattr(self.im, "info", None)
         if info is not None and hasattr(info, "set_projection_stall_exit"):
             before = getattr(info, "projection_stall_exit", False)       # (a caller's own setting survives this call)
