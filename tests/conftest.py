@@ -52,11 +52,11 @@ _ORDER_FIRST = (
     "test_ilqr.py::test_config5_rocket_projection_ilqr_as_stated",
     "test_abi.py::test_c_caller_computes_what_the_python_mirror_and_the_oracle_compute",
     "test_gpu_parity_sweep.py::",
-    "test_comm.py::",
 )
 _ORDER_LATE = ("test_examples.py::", "test_fd_validator.py::", "test_ilqr.py::test_rocket_example_as_shipped_nominal",
                "test_ilqr.py::test_cartpole_friction_example_on_the_device", "test_reference_golden.py::")
-_ORDER_LAST = ("test_model_generator.py::", "test_distributed.py::test_bench_force_dist_over_rccl_gpu")
+_ORDER_LAST = ("test_model_generator.py::", "test_comm.py::test_one_rank_allgather_over_rccl_gpu", "test_julia_shim_calls.py::test_communicator_sequence_gpu",
+               "test_distributed.py::test_bench_force_dist_over_rccl_gpu")
 
 
 def _order_class(nodeid):

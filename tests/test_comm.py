@@ -24,6 +24,13 @@ def _cleanup_shm():
             pass
 
 
+def _skip_without_rccl(lib):
+    """od_comm_* answer OD_ERR_UNSUPPORTED where librccl cannot be loaded: an environment without it skips, it does not fail"""
+    buf = (C.c_ubyte * 128)()
+    if lib.cdll.od_comm_unique_id(buf) == -2:
+        pytest.skip("librccl not loadable on this box: " + lib.cdll.od_last_error().decode())
+
+
 def _one_rank(lib, device):
     import bench
     import parity_checks as P
@@ -121,6 +128,7 @@ def test_one_rank_allgather_over_rccl_gpu(gpu_lib):
     """ncclCommInitRank + two ncclAllGather through od_comm_* on the MI355X (librccl resolved at run time), on the handle's stream right
     after the rollout that produced the arrays: bit-identical to them; the record goes to gpurun_out/od_comm_rccl.json"""
     import json
+    _skip_without_rccl(gpu_lib)
     X, G = _one_rank(gpu_lib, "cuda:0")
     d = os.path.join(ROOT, "gpurun_out")
     os.makedirs(d, exist_ok=True)
