@@ -107,11 +107,13 @@ int od_set_u_max(od_handle h, double u_max);
  * converged late.  The device-resident iLQR solver switches the exit on for its own launches (od_ilqr_options.proj_stall_exit,
  * default 1: a forward pass is 60 projections deep in lockstep), whatever the handle's setting. */
 int od_set_projection_stall_exit(od_handle h, int on);
-/* OD_F32 rocket handles (BASELINE config 5 asks for single precision): on = 1 (default) finishes every dynamics step with ONE
- * Newton step of the same residual in double at the single-precision solution and takes the implicit gradient -rz^{-1} rtheta
- * from that double factorisation; results are rounded to float on the way out.  States then agree with the double-precision
- * solve to float resolution (within the 1e-6 / 1e-4 bars); on = 0: single precision throughout (5e-4 / 2e-2).  The thrust-cone
- * projection stays in single precision either way (its result is kappa_tol = 1e-4 accurate by construction).  No effect on OD_F64. */
+/* OD_F32 rocket handles (BASELINE config 5 asks for single precision): on = 1 (default) refines every dynamics step with the residual
+ * of the same equations in double at the single-precision solution and takes the implicit gradient -rz^{-1} rtheta from a double
+ * factorisation there; and (since ABI 101) solves the thrust-cone projection in double on the float inputs -- an interior-point solve
+ * returns a point of its path, not a root, so a float solve agrees with the double one only to 2e-3 next to the apex of the cone and
+ * no final polish can repair it.  Results are rounded to float on the way out: states, projected controls and gradients are the
+ * double-precision handle's to float resolution (within the 1e-6 / 1e-4 bars).  on = 0: single precision throughout (states 5e-4,
+ * projected controls 2e-3, gradients 2e-2), the faster forward pass.  No effect on OD_F64. */
 int od_set_mixed_precision(od_handle h, int on);
 int od_set_layout(od_handle h, int layout);
 /* A handle runs on one stream at a time (its gradient hand-over and staging workspaces are reused by consecutive
@@ -394,7 +396,13 @@ int od_rocket(od_handle h, long B, int project, const void* x, const void* u, vo
 /* soc_projection / soc_projection_gradient (src/models/rocket/dynamics.jl:168-214) on an OD_ROCKET_DYNAMICS
  * handle: Euclidean projection of u (3 per problem) onto the thrust cone {|u_1:2| <= u_3 <= u_max} by the
  * interior-point solve the reference uses (z0 and options of :169-175).  uproj: 3; duproj: 3 x 3 col-major
- * d uproj / d u (NULL = diff_sol false); status bits 16 / 32 = state / gradient converged. */
+ * d uproj / d u (NULL = diff_sol false); status bits 16 / 32 = state / gradient converged.
+ * The reference runs this solve with eps_min = 0: every step goes all the way to the boundary of an orthant, and a literal
+ * floating-point transcription of the loop then reads rounding noise in three places (where the blocking variable lands, the sign of
+ * the next affine direction of a variable at zero, the line search's r_c <= r_vio between two residuals that are exactly zero).  The
+ * solve here completes each as EXACT arithmetic has it -- blocking variable exactly zero, that variable's direction from its own
+ * complementarity row, first trial accepted on the linear equality rows -- and follows the exact-arithmetic path (binary128) to 1e-7
+ * on 99.95 % of controls; a literal double-precision loop stays on it on ~95 %. */
 int od_soc_project(od_handle h, long B, const void* u, void* uproj, void* duproj, int* status);
 /* the same solve with its whole solution: z (10 per problem) = [u_proj (3), p, s, w, y, v (3)] of the projection's KKT system
  * (src/models/rocket/codegen.jl:45-64) -- the iterate soc_projection_gradient differentiates at (ip.z, dynamics.jl:180-185; the
