@@ -322,6 +322,39 @@ def main():
         e2, k2, st2, it2, B2 = timed_region("strong")
         strong = dict(scaling="strong", total_batch=args.batch, rollouts_per_gpu=B2, value=args.batch * T * args.steps / e2,
                       unit="steps+grads/s", ms_per_step=e2 / args.steps * 1e3, kernel_ms_rank0=k2)
+    # N > 1 without --gather (the driver's scaling command): after the headline region, the same K steps once more WITH the path's one
+    # exchange -- od_allgather_compact over RCCL behind the C ABI after every step -- so that one invocation per N also yields what the
+    # collective costs over xGMI.  Reported beside `value`, never in it; a failure here (librccl absent, rendezvous) is recorded, not raised.
+    with_gather = None
+    if world > 1 and comm is None and args.scaling == "weak":
+        try:
+            from optimization_dynamics_amd.parallel import Communicator
+            box = [None]
+            if rank == 0:
+                try:
+                    box = [Communicator.unique_id(im.lib)]
+                except Exception as e:       # noqa: BLE001  (every rank must leave the broadcast below)
+                    box = ["error: " + repr(e)[:200]]
+            dist.broadcast_object_list(box, src=0)
+            if not isinstance(box[0], bytes):
+                raise RuntimeError(str(box[0]))
+            try:
+                comm = Communicator(im, box[0], rank, world)
+            except Exception:                # noqa: BLE001
+                comm = None
+            agreed = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)        # all ranks time the gather, or none does (no rank left waiting in a collective)
+            if agreed.item() < 1.0:
+                comm = None
+                raise RuntimeError("od_comm_create failed on at least one rank")
+            e3, k3, _, _, B3 = timed_region("weak")
+            with_gather = dict(collective="od_allgather_compact: ncclAllGather x 2 behind the C ABI (od_comm_*)", ranks_seen=comm.world,
+                               value=world * args.batch * T * args.steps / e3, unit="steps+grads/s", ms_per_step=e3 / args.steps * 1e3,
+                               gathered_bytes_per_rank_per_step=8 * (8 * (T + 1) + 40 * T) * B3 * world)
+        except Exception as e:           # noqa: BLE001
+            with_gather = dict(error=repr(e)[:300])
+        finally:
+            comm = None
 
     units_per_rank = B * T
     total_units = (world * args.batch if args.scaling == "weak" else args.batch) * T
@@ -409,6 +442,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "ranks_seen": (comm.world if comm is not None else dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else "none (single process)"),
             "collective": ("od_allgather_compact: ncclAllGather x 2 behind the C ABI (od_comm_*), ranks_seen = ncclCommCount" if comm is not None else None),
+            "with_gather": with_gather,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "hopper (RoboDojo path-following contact), T=%d, batch=%d rollouts %s, "
                                    "h=0.05, kappa_eval=1e-4, kappa_grad=1e-3, r_tol=1e-8; od_rollout_compact = f+fx+fu per knot (q3, dq3/d(q1,q2,u))"

@@ -129,6 +129,17 @@ def test_bench_gpus_flag_spawns_ranks(emu_lib):
     assert rec["value"] > 0 and "all-gather" in rec["config"]["parallelism"]
 
 
+def test_scaling_command_also_times_the_gather(emu_lib):
+    """the driver's scaling command carries no --gather: a run on N > 1 ranks times, after the headline region, the same steps once more
+    with od_allgather_compact after every step and reports them beside `value` (`with_gather`), so one invocation per N yields the
+    collective's cost too; a single-rank run has no such block"""
+    rec = _run_bench(emu_lib, ["--gpus", "2"])
+    wg = rec["with_gather"]
+    assert wg and wg["ranks_seen"] == 2 and wg["value"] > 0 and "od_allgather_compact" in wg["collective"], wg
+    assert wg["gathered_bytes_per_rank_per_step"] == 8 * (8 * 7 + 40 * 6) * 16 * 2
+    assert rec["collective"] is None and rec["strong_scaling"]["value"] > 0          # the headline itself: no collective
+
+
 def _run_bench(emu_lib, extra, timeout=600):
     import json
     import subprocess
