@@ -15,7 +15,9 @@ of `--batch` (block k drawn with seed k; block 0 is the single-GPU workload):
 A weak run on N > 1 ranks times the strong mode as well (same K steps, after the headline region) and reports it under
 "strong_scaling", so one driver invocation per N yields both curves.
 `--gather` adds the one exchange the path can have, the all-gather of the linearisation for an outer
-loop that runs elsewhere, in compact form (x+ and dq3/d(q1,q2,u): 2.4x fewer bytes than x+, A, B).
+loop that runs elsewhere, in compact form (x+ and dq3/d(q1,q2,u): 2.4x fewer bytes than x+, A, B), through the product's own
+entry points (od_comm_* / od_allgather_compact: RCCL behind the C ABI).  Without the flag a run on N > 1 ranks times the steps
+once more WITH the gather after the headline region and reports them under "with_gather" (never in `value`).
 
 Launch: under `python -m torch.distributed.run ... bench.py --gpus N` (RANK / WORLD_SIZE in the
 environment) this process is one rank; `python bench.py --gpus N` on its own re-executes itself under
