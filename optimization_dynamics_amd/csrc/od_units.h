@@ -592,12 +592,6 @@ template <class S> struct CastSinkFull64 {
   OD_HD void defer(const double*, double) {}
   OD_HD void grad(int i, int c, double v) { s.grad(i, c, (float)v); }
 };
-template <class T> struct FullStateNoGradSink {
-  static constexpr bool DEFER_GRAD = true;     // (never asked for a gradient: no gradient code in the kernel)
-  static constexpr bool FULL_STATE = true;
-  OD_HD void grad(int, int, T) {}
-  OD_HD void defer(const T*, T) {}
-};
 // zp: in = the initial guess soc_projection prescribes (MP::ZI_VAL), out = the whole solution vector; GRAD = false: kernels that never take the projection's gradient
 template <class MP, bool GRAD, class T, class Sink>
 OD_HD int soc_project_solve(const RocketArgs<T>& a, const T* thp, T* zp, bool want_grad, Sink& sink, int* itp) {
@@ -613,7 +607,7 @@ OD_HD int soc_project_solve(const RocketArgs<T>& a, const T* thp, T* zp, bool wa
         CastSinkFull64<Sink> cs{sink};
         st = ip_step_grad<MP>(a.opts_proj64, th, z, true, want_grad, cs, itp, a.proj_stall_exit != 0);
       } else {
-        FullStateNoGradSink<double> ns;
+        NoGradSink<double> ns;             // (state only: the projected control z[0..2] is all the rollout kernels take, and all the snapshot keeps)
         st = ip_step_grad<MP>(a.opts_proj64, th, z, true, false, ns, itp, a.proj_stall_exit != 0);
       }
 #pragma unroll
