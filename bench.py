@@ -326,9 +326,12 @@ def main():
                       unit="steps+grads/s", ms_per_step=e2 / args.steps * 1e3, kernel_ms_rank0=k2)
     # N > 1 without --gather (the driver's scaling command): after the headline region, the same K steps once more WITH the path's one
     # exchange -- od_allgather_compact over RCCL behind the C ABI after every step -- so that one invocation per N also yields what the
-    # collective costs over xGMI.  Reported beside `value`, never in it; a failure here (librccl absent, rendezvous) is recorded, not raised.
-    with_gather = None
-    if world > 1 and comm is None and args.scaling == "weak":
+    # collective costs over xGMI.  Reported beside `value`, never in it; a failure here (librccl absent, rendezvous) is recorded, not raised,
+    # and a leg that does not finish (a rendezvous that hangs) is cut off by a watchdog on every rank: rank 0 prints the line it has.
+    def gather_leg():
+        nonlocal comm
+        if os.environ.get("OD_BENCH_TEST_HANG_GATHER_LEG"):      # TEST HARNESS ONLY (tests/test_distributed.py): a rendezvous that never returns
+            time.sleep(3600)
         try:
             from optimization_dynamics_amd.parallel import Communicator
             box = [None]
@@ -350,13 +353,35 @@ def main():
                 comm = None
                 raise RuntimeError("od_comm_create failed on at least one rank")
             e3, k3, _, _, B3 = timed_region("weak")
-            with_gather = dict(collective="od_allgather_compact: ncclAllGather x 2 behind the C ABI (od_comm_*)", ranks_seen=comm.world,
-                               value=world * args.batch * T * args.steps / e3, unit="steps+grads/s", ms_per_step=e3 / args.steps * 1e3,
-                               gathered_bytes_per_rank_per_step=8 * (8 * (T + 1) + 40 * T) * B3 * world)
+            return dict(collective="od_allgather_compact: ncclAllGather x 2 behind the C ABI (od_comm_*)", ranks_seen=comm.world,
+                        value=world * args.batch * T * args.steps / e3, unit="steps+grads/s", ms_per_step=e3 / args.steps * 1e3,
+                        gathered_bytes_per_rank_per_step=8 * (8 * (T + 1) + 40 * T) * B3 * world)
         except Exception as e:           # noqa: BLE001
-            with_gather = dict(error=repr(e)[:300])
+            return dict(error=repr(e)[:300])
         finally:
             comm = None
+
+    want_gather_leg = world > 1 and comm is None and args.scaling == "weak"
+    line = None
+
+    def run_gather_leg():
+        """every rank, just before rank 0 prints: -> the with_gather block (None when the leg does not apply)"""
+        if not want_gather_leg:
+            return None
+        import threading
+        done = threading.Event()
+        limit = float(os.environ.get("OD_BENCH_GATHER_LEG_TIMEOUT", "120"))
+
+        def watchdog():
+            if not done.wait(limit):
+                if rank == 0 and line is not None:
+                    line["with_gather"] = dict(error="the gather leg did not finish in %.0f s (RCCL rendezvous / collective); cut off -- the headline figures above are unaffected" % limit)
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        r = gather_leg()
+        done.set()
+        return r
 
     units_per_rank = B * T
     total_units = (world * args.batch if args.scaling == "weak" else args.batch) * T
@@ -444,7 +469,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "ranks_seen": (comm.world if comm is not None else dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else "none (single process)"),
             "collective": ("od_allgather_compact: ncclAllGather x 2 behind the C ABI (od_comm_*), ranks_seen = ncclCommCount" if comm is not None else None),
-            "with_gather": with_gather,
+            "with_gather": None,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "hopper (RoboDojo path-following contact), T=%d, batch=%d rollouts %s, "
                                    "h=0.05, kappa_eval=1e-4, kappa_grad=1e-3, r_tol=1e-8; od_rollout_compact = f+fx+fu per knot (q3, dq3/d(q1,q2,u))"
@@ -499,6 +524,9 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(B, T, seed=0)
             except Exception as e:   # the oracle is a reported baseline, never a dependency of the timed path
                 line["cpu_baseline"] = {"value": None, "unit": "steps+grads/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+    wg = run_gather_leg()
+    if rank == 0:
+        line["with_gather"] = wg
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -140,6 +140,16 @@ def test_scaling_command_also_times_the_gather(emu_lib):
     assert rec["collective"] is None and rec["strong_scaling"]["value"] > 0          # the headline itself: no collective
 
 
+def test_a_gather_leg_that_hangs_does_not_take_the_line_down(emu_lib, monkeypatch):
+    """the watchdog of the extra gather leg: if the leg does not finish (an RCCL rendezvous that never returns, simulated) every rank
+    leaves after the limit, rank 0 having printed the headline line with the cut-off noted -- exit code 0, one JSON line"""
+    monkeypatch.setenv("OD_BENCH_TEST_HANG_GATHER_LEG", "1")
+    monkeypatch.setenv("OD_BENCH_GATHER_LEG_TIMEOUT", "3")
+    rec = _run_bench(emu_lib, ["--gpus", "2"])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["strong_scaling"]["value"] > 0
+    assert "did not finish" in rec["with_gather"]["error"]
+
+
 def _run_bench(emu_lib, extra, timeout=600):
     import json
     import subprocess
