@@ -324,6 +324,19 @@ def main():
         e2, k2, st2, it2, B2 = timed_region("strong")
         strong = dict(scaling="strong", total_batch=args.batch, rollouts_per_gpu=B2, value=args.batch * T * args.steps / e2,
                       unit="steps+grads/s", ms_per_step=e2 / args.steps * 1e3, kernel_ms_rank0=k2)
+    # BASELINE config 4 as worded -- "hopper gait, batch = 8192 rollouts sharded across 8 x MI355X" -- on N > 1 ranks: the FIXED batch of 8192
+    # (block 0 of the workload at that block size) sharded over the ranks, same K steps, beside the headline's figures
+    config4 = None
+    if world > 1 and args.scaling == "weak" and not args.gather and 8192 % world == 0 and args.batch != 8192:
+        keep = args.batch
+        args.batch = 8192
+        try:
+            e4, k4, _, _, B4 = timed_region("strong")
+            config4 = dict(workload="BASELINE config 4: hopper, 8192 rollouts x T = %d sharded over %d GPUs (strong scaling)" % (T, world), rollouts_per_gpu=B4,
+                           value=8192 * T * args.steps / e4, unit="steps+grads/s", ms_per_step=e4 / args.steps * 1e3, kernel_ms_rank0=k4)
+        finally:
+            args.batch = keep
+
     # N > 1 without --gather (the driver's scaling command): after the headline region, the same K steps once more WITH the path's one
     # exchange -- od_allgather_compact over RCCL behind the C ABI after every step -- so that one invocation per N also yields what the
     # collective costs over xGMI.  Reported beside `value`, never in it; a failure here (librccl absent, rendezvous) is recorded, not raised,
@@ -504,6 +517,8 @@ def main():
         }
         if strong is not None:
             line["strong_scaling"] = strong
+        if config4 is not None:
+            line["config4_sharded"] = config4
         for key_, blk in (("aux_config_4", aux_c4), ("aux_large_batch_rollouts", aux_roll)):
             if blk is not None:
                 Fr_, _, _ = algorithmic_flops_per_unit(blk["mean_iterations"], stats)

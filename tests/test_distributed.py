@@ -138,6 +138,8 @@ def test_scaling_command_also_times_the_gather(emu_lib):
     assert wg and wg["ranks_seen"] == 2 and wg["value"] > 0 and "od_allgather_compact" in wg["collective"], wg
     assert wg["gathered_bytes_per_rank_per_step"] == 8 * (8 * 7 + 40 * 6) * 16 * 2
     assert rec["collective"] is None and rec["strong_scaling"]["value"] > 0          # the headline itself: no collective
+    c4 = rec["config4_sharded"]                                                       # BASELINE config 4 as worded: 8192 rollouts over the ranks
+    assert c4["rollouts_per_gpu"] == 4096 and c4["value"] > 0
 
 
 def test_a_gather_leg_that_hangs_does_not_take_the_line_down(emu_lib, monkeypatch):
