@@ -337,6 +337,32 @@ def main():
         finally:
             args.batch = keep
 
+    # BASELINE config 5 as worded -- "rocket thrust-cone SOCP step inside full iLQR outer loop with implicit grads, fp32, 8 x MI355X" -- on
+    # N > 1 ranks: 4096 independent landing problems sharded over the ranks (every problem an independent solve: no collective in the
+    # iteration), the device-resident iteration timed per rank, the slowest rank's time reported.  No collective inside the leg; what each
+    # rank measured (or that it failed) is agreed on by ONE all-reduce afterwards, so no rank is left waiting.
+    config5 = None
+    if world > 1 and args.scaling == "weak" and not args.gather and not emu and not args.no_aux_configs and 4096 % world == 0:
+        ms5 = -1.0
+        try:
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+            import bench_configs
+            r5, _, _ = bench_configs._config5_one(dev, "examples/rocket.jl inputs", torch.float32, False, B=4096 // world)
+            ms5 = float(r5["ms_per_iteration"])
+        except Exception as e:               # noqa: BLE001
+            r5 = dict(error=repr(e)[:300])
+        t5 = torch.tensor([ms5, -ms5], dtype=torch.float64, device=dev)
+        dist.all_reduce(t5, op=dist.ReduceOp.MAX)
+        slow, fast = float(t5[0].item()), -float(t5[1].item())
+        if fast > 0:                         # every rank measured
+            n_units = (4096 // world) * world * 60 * 12         # 11 candidates' state steps + the linearisation's step per knot
+            config5 = dict(workload="BASELINE config 5: rocket landing with the thrust-cone projection inside the iLQR iteration on the device, fp32 (mixed precision: "
+                                    "projection and refinement in double), 4096 problems sharded over %d GPUs, 11 step sizes, T = 61, inputs of examples/rocket.jl" % world,
+                           problems_per_gpu=4096 // world, ms_per_iteration_slowest_rank=slow, ms_per_iteration_fastest_rank=fast,
+                           value=n_units / (slow * 1e-3), unit="projected rocket steps/s (all ranks)")
+        else:
+            config5 = dict(error="at least one rank could not run the leg", rank0=r5 if isinstance(r5, dict) and "error" in r5 else None)
+
     # N > 1 without --gather (the driver's scaling command): after the headline region, the same K steps once more WITH the path's one
     # exchange -- od_allgather_compact over RCCL behind the C ABI after every step -- so that one invocation per N also yields what the
     # collective costs over xGMI.  Reported beside `value`, never in it; a failure here (librccl absent, rendezvous) is recorded, not raised,
@@ -519,6 +545,8 @@ def main():
             line["strong_scaling"] = strong
         if config4 is not None:
             line["config4_sharded"] = config4
+        if config5 is not None:
+            line["config5_sharded"] = config5
         for key_, blk in (("aux_config_4", aux_c4), ("aux_large_batch_rollouts", aux_roll)):
             if blk is not None:
                 Fr_, _, _ = algorithmic_flops_per_unit(blk["mean_iterations"], stats)
