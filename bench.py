@@ -341,13 +341,18 @@ def main():
     # N > 1 ranks: 4096 independent landing problems sharded over the ranks (every problem an independent solve: no collective in the
     # iteration), the device-resident iteration timed per rank, the slowest rank's time reported.  No collective inside the leg; what each
     # rank measured (or that it failed) is agreed on by ONE all-reduce afterwards, so no rank is left waiting.
-    config5 = None
-    if world > 1 and args.scaling == "weak" and not args.gather and not emu and not args.no_aux_configs and 4096 % world == 0:
-        ms5 = -1.0
+    stub5 = bool(os.environ.get("OD_BENCH_TEST_CONFIG5_STUB"))         # TEST HARNESS ONLY: the leg's glue on the host build, the measurement replaced by a constant
+    want_config5_leg = world > 1 and args.scaling == "weak" and not args.gather and (not emu or stub5) and not args.no_aux_configs and 4096 % world == 0
+
+    def config5_leg():
+        ms5, r5 = -1.0, None
         try:
             sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
             import bench_configs
-            r5, _, _ = bench_configs._config5_one(dev, "examples/rocket.jl inputs", torch.float32, False, B=4096 // world)
+            if stub5:
+                r5 = dict(ms_per_iteration=1.0 + rank)
+            else:
+                r5, _, _ = bench_configs._config5_one(dev, "examples/rocket.jl inputs", torch.float32, False, B=4096 // world)
             ms5 = float(r5["ms_per_iteration"])
         except Exception as e:               # noqa: BLE001
             r5 = dict(error=repr(e)[:300])
@@ -356,12 +361,11 @@ def main():
         slow, fast = float(t5[0].item()), -float(t5[1].item())
         if fast > 0:                         # every rank measured
             n_units = (4096 // world) * world * 60 * 12         # 11 candidates' state steps + the linearisation's step per knot
-            config5 = dict(workload="BASELINE config 5: rocket landing with the thrust-cone projection inside the iLQR iteration on the device, fp32 (mixed precision: "
+            return dict(workload="BASELINE config 5: rocket landing with the thrust-cone projection inside the iLQR iteration on the device, fp32 (mixed precision: "
                                     "projection and refinement in double), 4096 problems sharded over %d GPUs, 11 step sizes, T = 61, inputs of examples/rocket.jl" % world,
                            problems_per_gpu=4096 // world, ms_per_iteration_slowest_rank=slow, ms_per_iteration_fastest_rank=fast,
                            value=n_units / (slow * 1e-3), unit="projected rocket steps/s (all ranks)")
-        else:
-            config5 = dict(error="at least one rank could not run the leg", rank0=r5 if isinstance(r5, dict) and "error" in r5 else None)
+        return dict(error="at least one rank could not run the leg", rank0=r5 if isinstance(r5, dict) and "error" in r5 else None)
 
     # N > 1 without --gather (the driver's scaling command): after the headline region, the same K steps once more WITH the path's one
     # exchange -- od_allgather_compact over RCCL behind the C ABI after every step -- so that one invocation per N also yields what the
@@ -403,24 +407,34 @@ def main():
     want_gather_leg = world > 1 and comm is None and args.scaling == "weak"
     line = None
 
-    def run_gather_leg():
-        """every rank, just before rank 0 prints: -> the with_gather block (None when the leg does not apply)"""
-        if not want_gather_leg:
-            return None
+    def run_extra_legs():
+        """every rank, just before rank 0 prints: -> (with_gather, config5_sharded) blocks (None where a leg does not apply).  The legs run
+        under a watchdog: whatever has not finished after the limit is cut off, rank 0 prints the line it has, every rank leaves"""
+        if not (want_gather_leg or want_config5_leg):
+            return None, None
         import threading
         done = threading.Event()
-        limit = float(os.environ.get("OD_BENCH_GATHER_LEG_TIMEOUT", "120"))
+        limit = float(os.environ.get("OD_BENCH_GATHER_LEG_TIMEOUT", "180"))
+        got = {}
 
         def watchdog():
             if not done.wait(limit):
                 if rank == 0 and line is not None:
-                    line["with_gather"] = dict(error="the gather leg did not finish in %.0f s (RCCL rendezvous / collective); cut off -- the headline figures above are unaffected" % limit)
+                    cut = dict(error="did not finish within %.0f s of the extra legs' start (RCCL rendezvous / collective / a rank that fell over); cut off -- the headline figures above are unaffected" % limit)
+                    line["with_gather"] = got.get("wg", cut if want_gather_leg else None)
+                    line["config5_sharded"] = got.get("c5", cut if want_config5_leg else None)
                     print(json.dumps(line), flush=True)
                 os._exit(0)
         threading.Thread(target=watchdog, daemon=True).start()
-        r = gather_leg()
+        if want_gather_leg:
+            got["wg"] = gather_leg()
+        if want_config5_leg:
+            try:
+                got["c5"] = config5_leg()
+            except Exception as e:           # noqa: BLE001  (e.g. the agreeing all-reduce on a context an earlier failure poisoned)
+                got["c5"] = dict(error=repr(e)[:300])
         done.set()
-        return r
+        return got.get("wg"), got.get("c5")
 
     units_per_rank = B * T
     total_units = (world * args.batch if args.scaling == "weak" else args.batch) * T
@@ -545,8 +559,6 @@ def main():
             line["strong_scaling"] = strong
         if config4 is not None:
             line["config4_sharded"] = config4
-        if config5 is not None:
-            line["config5_sharded"] = config5
         for key_, blk in (("aux_config_4", aux_c4), ("aux_large_batch_rollouts", aux_roll)):
             if blk is not None:
                 Fr_, _, _ = algorithmic_flops_per_unit(blk["mean_iterations"], stats)
@@ -567,9 +579,11 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(B, T, seed=0)
             except Exception as e:   # the oracle is a reported baseline, never a dependency of the timed path
                 line["cpu_baseline"] = {"value": None, "unit": "steps+grads/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
-    wg = run_gather_leg()
+    wg, c5 = run_extra_legs()
     if rank == 0:
         line["with_gather"] = wg
+        if c5 is not None:
+            line["config5_sharded"] = c5
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

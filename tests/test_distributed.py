@@ -129,6 +129,16 @@ def test_bench_gpus_flag_spawns_ranks(emu_lib):
     assert rec["value"] > 0 and "all-gather" in rec["config"]["parallelism"]
 
 
+def test_scaling_command_config5_leg_glue(emu_lib, monkeypatch):
+    """the config-5 leg of an N > 1 run needs the MI355X (device-resident iLQR iteration); its glue -- per-rank measurement, ONE agreeing
+    all-reduce, the block in the line, composition with the gather leg under one watchdog -- runs here with the measurement stubbed"""
+    monkeypatch.setenv("OD_BENCH_TEST_CONFIG5_STUB", "1")
+    rec = _run_bench(emu_lib, ["--gpus", "2"])
+    c5 = rec["config5_sharded"]
+    assert c5["problems_per_gpu"] == 2048 and c5["ms_per_iteration_slowest_rank"] == 2.0 and c5["ms_per_iteration_fastest_rank"] == 1.0
+    assert abs(c5["value"] - 4096 * 60 * 12 / 2e-3) < 1e-3 and rec["with_gather"]["ranks_seen"] == 2
+
+
 def test_scaling_command_also_times_the_gather(emu_lib):
     """the driver's scaling command carries no --gather: a run on N > 1 ranks times, after the headline region, the same steps once more
     with od_allgather_compact after every step and reports them beside `value` (`with_gather`), so one invocation per N yields the
