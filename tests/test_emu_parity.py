@@ -285,3 +285,11 @@ def test_solutions_zero_the_hand_written_residuals(oracle, emu_lib, name):
 
 def test_rocket_solutions_zero_the_hand_written_residuals(oracle, emu_lib):
     P.check_rocket_solutions_against_hand_written_residuals(oracle, emu_lib, "cpu", B=256)
+
+
+def test_every_knot_of_hopper_rollouts_host_build(oracle, emu_lib):
+    """the CPU twin of test_gpu_parity.py::test_headline_rollout_every_knot_passes_the_stopping_test: 1024 rollouts x 100 knots on the host
+    build -- 1e-6 between the rollout kernel and the independent-knot kernel wherever both stop at the same iteration, stopping ties
+    identified by their iteration counts, every solution under the oracle's residual"""
+    P.check_every_knot(oracle, emu_lib, "cpu", 1024, 100)
+
