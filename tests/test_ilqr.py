@@ -157,6 +157,12 @@ def test_config5_rocket_projection_ilqr_as_stated(oracle, gpu_lib):
     C.check_config5(oracle, gpu_lib, "cuda:0", B=1024, iters=12)
 
 
+def test_config5_rocket_projection_ilqr_host_build(oracle, emu_lib):
+    """the CPU twin of test_config5_rocket_projection_ilqr_as_stated: the same checks (chained rollouts against the oracle's own chain, the
+    Riccati pass against numpy, device iteration against the host-composed loop, single against double precision) at 64 problems"""
+    C.check_config5(oracle, emu_lib, "cpu", B=64, iters=6)
+
+
 def test_rocket_example_with_its_constraints_cpu(emu_lib):
     """examples/rocket.jl `:projection` in full (stage inequality, terminal box and equalities) through od_ilqr_solve, one problem"""
     C.check_rocket_example(emu_lib, "cpu", B=1)
