@@ -372,7 +372,9 @@ int od_ls_fit(od_handle h, long B, int N, int ny, int nzb, const void* eta, cons
 
 /* interior_point_solve!(ip) on caller-provided z0, theta (src/models/rocket/dynamics.jl:109,178):
  * z: nz per problem; dz: nzq x ngc per problem (rows = solution block, cols = leading theta
- * columns, see od_raw_grad_dims); dz may be NULL (diff_sol = false). */
+ * columns, see od_raw_grad_dims); dz may be NULL (diff_sol = false).  This is the generic loop as the literal restatement has it, for
+ * any model of the table -- for OD_ROCKET_PROJECTION too: the generated elimination with its pivoted tail, the literal line search;
+ * od_soc_project / od_rocket are the entry points that complete that solve's eps_min = 0 steps as exact arithmetic has them. */
 int od_raw_grad_dims(int model, int* nzq, int* ngc);
 
 /* The whole solution of a step: z (nz per problem) at kappa_eval and dz = d z / d(q1, q2, u1)
